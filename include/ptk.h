@@ -1,0 +1,242 @@
+/*
+ * ptk.h — C ABI of the MI355X path-tracing kernel library (libptk.so).
+ *
+ * This is the drop-in boundary between host C++ (the re-authored rt:: API in
+ * pathtracing_amd/host, which mirrors the reference's Pathtracing library) and
+ * the hand-written gfx950 HIP kernels.  POD only, plain pointers and sizes, int
+ * status (0 = ok), no exceptions cross it.  Every entry point cites the
+ * reference interface (file:line under /root/reference) whose work it takes
+ * over.  The reference has no FFI of its own (it is one C++17 static library,
+ * premake5.lua:106-124); these are the calls its `abstract_pathtracer::run`
+ * driver thread makes once the per-pixel loop is moved to the GPU.
+ *
+ * Conventions
+ *   - all matrices are column-major float[16] exactly as glm::mat4 stores them
+ *     (m[col*4+row]);
+ *   - all arithmetic is IEEE fp32, kernels are built with -ffp-contract=off so
+ *     hit decisions replay the reference's x86-64 -O2 arithmetic bit for bit;
+ *   - pointers named *_dev are device (HBM) pointers on the context's GPU,
+ *     everything else is host memory that the library copies during the call;
+ *   - one context per driver thread; calls on one context are serialised by the
+ *     caller.  Work is enqueued on the context's stream (ptk_ctx_set_stream);
+ *     calls that return host data synchronise that stream, the *_dev calls do not.
+ */
+#ifndef PTK_H
+#define PTK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTK_OK 0
+#define PTK_ERR_INVALID 1   /* bad argument / shape mismatch                   */
+#define PTK_ERR_HIP 2       /* a HIP runtime call failed (see ptk_last_error)  */
+#define PTK_ERR_STATE 3     /* call made in the wrong order (no scene, ...)     */
+#define PTK_ERR_NOMEM 4
+
+#define PTK_MAX_DEPTH 5u        /* pathtracer.cpp:16  trace_recursive(..., 5)    */
+#define PTK_EPSILON 1e-3f       /* pathtracer.h:19    s_epsilon                  */
+#define PTK_KD_MAX_DEPTH 100u   /* scene.cpp:220                                 */
+
+/* rt::vertex, scene.h:40-45 (32 B, same member order). */
+typedef struct ptk_vertex {
+    float position[3];
+    float normal[3];
+    float uv[2];
+} ptk_vertex;
+
+/* rt::triangle::vertices, scene.h:101 (the private precomputed members of
+ * scene.h:123-126 are rebuilt by the library, scene.cpp:91-107). */
+typedef struct ptk_triangle {
+    ptk_vertex v[3];
+} ptk_triangle;
+
+/* rt::mesh as the caller sees it: mesh::add_triangle order, scene.h:262-268. */
+typedef struct ptk_mesh_desc {
+    const ptk_triangle* triangles;
+    uint64_t num_triangles;
+} ptk_mesh_desc;
+
+enum { PTK_SAMPLER_COLOR = 0, PTK_SAMPLER_IMAGE = 1 };          /* sampler.h:48,73 */
+enum { PTK_MODE_LINEAR = 0, PTK_MODE_NEAREST = 1 };             /* sampler.h:65-68 */
+enum { PTK_SHAPE_SPHERE = 0, PTK_SHAPE_MESH = 1 };              /* scene.h:231,244 */
+enum { PTK_BACKGROUND_COLOR = 0, PTK_BACKGROUND_EQUIRECT = 1 }; /* sampler.h:48,145 */
+
+/* rt::image pixel store, sampler.h:138-139: row-major float RGB, row 0 is the
+ * row image::load put first (bottom of the file, sampler.cpp:81). */
+typedef struct ptk_texture_desc {
+    uint32_t width, height;
+    const float* rgb; /* width*height*3 floats */
+} ptk_texture_desc;
+
+/* rt::sampler_2d: color_sampler (sampler.h:48-63) or image (sampler.h:73-140). */
+typedef struct ptk_sampler_desc {
+    uint32_t kind;    /* PTK_SAMPLER_*                       */
+    float color[3];   /* PTK_SAMPLER_COLOR                   */
+    uint32_t texture; /* PTK_SAMPLER_IMAGE: index in textures */
+    uint32_t mode;    /* PTK_MODE_*  (image::sample_mode)     */
+} ptk_sampler_desc;
+
+/* rt::scene_node, scene.h:284-350: the three matrices update_matrices keeps
+ * (scene.cpp:295-299) + shape + the four material samplers (scene.h:133-140). */
+typedef struct ptk_node_desc {
+    float transform[16];
+    float inv_transform[16];
+    float normal_transform[16];
+    uint32_t shape_kind; /* PTK_SHAPE_*                */
+    uint32_t mesh;       /* PTK_SHAPE_MESH: mesh index */
+    uint32_t albedo, emission, roughness, metallic; /* sampler indices */
+} ptk_node_desc;
+
+/* rt::scene::background (scene.h:369): color_sampler or equirectangular_map. */
+typedef struct ptk_background_desc {
+    uint32_t kind;    /* PTK_BACKGROUND_* */
+    float color[3];
+    uint32_t texture; /* PTK_BACKGROUND_EQUIRECT */
+    uint32_t mode;
+} ptk_background_desc;
+
+/* rt::camera, scene.h:27-37 (direction already normalised by set_direction). */
+typedef struct ptk_camera_desc {
+    float position[3];
+    float direction[3];
+} ptk_camera_desc;
+
+/* rt::scene, scene.h:355-394, flattened to tables. */
+typedef struct ptk_scene_desc {
+    const ptk_node_desc* nodes;
+    uint32_t num_nodes;
+    const ptk_mesh_desc* meshes;
+    uint32_t num_meshes;
+    const ptk_sampler_desc* samplers;
+    uint32_t num_samplers;
+    const ptk_texture_desc* textures;
+    uint32_t num_textures;
+    ptk_background_desc background;
+    ptk_camera_desc camera;
+} ptk_scene_desc;
+
+/* One node of the flattened KD-tree, DFS preorder (left subtree, then right),
+ * exactly the order mesh::intersect_internal visits (scene.cpp:188-212).
+ * `skip` = index of the first node after this node's subtree, so the
+ * reference's recursion becomes: hit box -> i+1, miss box -> skip. */
+typedef struct ptk_kd_node {
+    float bmin[3];
+    float bmax[3];
+    uint32_t skip;
+    uint32_t first_prim; /* offset into the mesh's leaf-ordered prim list */
+    uint32_t num_prims;  /* 0 for interior nodes (scene.cpp:280-284)      */
+    uint32_t depth;
+} ptk_kd_node;
+
+typedef struct ptk_kd_info {
+    uint32_t num_nodes;
+    uint32_t num_leaves;
+    uint64_t num_leaf_prims; /* sum of leaf sizes (triangles are duplicated) */
+    uint32_t max_depth;
+    float bmin[3], bmax[3];  /* mesh::m_bounds, scene.cpp:123-137 */
+} ptk_kd_info;
+
+typedef struct ptk_counters {
+    uint64_t paths; /* trace() calls (pathtracer.cpp:14)                      */
+    uint64_t rays;  /* scene::cast_ray calls (scene.cpp:355), <= 5 per path   */
+} ptk_counters;
+
+typedef struct ptk_ctx ptk_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device`.  No reference counterpart (the
+ * reference has no device); stands where pathtracer_result's driver thread is
+ * created, abstract_pathtracer.cpp:121-125. */
+int ptk_ctx_create(int device, ptk_ctx** out);
+void ptk_ctx_destroy(ptk_ctx* ctx);
+/* Last error text of `ctx` (or of the last failed ptk_ctx_create if NULL). */
+const char* ptk_last_error(const ptk_ctx* ctx);
+/* Use `hip_stream` (a hipStream_t) for all later work; NULL = the context's own. */
+int ptk_ctx_set_stream(ptk_ctx* ctx, void* hip_stream);
+int ptk_ctx_synchronize(ptk_ctx* ctx);
+
+/* ---- scene ---------------------------------------------------------------
+ * Replaces scene::compile (scene.cpp:331-348) -> mesh::compile
+ * (scene.cpp:123-140) -> kd_tree_node ctor (scene.cpp:214-286) and
+ * triangle::update (scene.cpp:91-107): builds each mesh's KD-tree with the
+ * reference's topology on the host, flattens it and uploads every table to HBM. */
+int ptk_scene_upload(ptk_ctx* ctx, const ptk_scene_desc* scene);
+/* Only the camera changed (Sandbox orbit camera, rtsb.cpp:295-299). */
+int ptk_scene_set_camera(ptk_ctx* ctx, const ptk_camera_desc* camera);
+
+/* Host-side KD build alone (no GPU needed): kd_tree_node ctor, scene.cpp:214-286.
+ * Two-call pattern: nodes/prims may be NULL to query sizes via `info`.
+ * prims[k] = index into `triangles` of the k-th leaf-ordered primitive. */
+int ptk_kd_build(const ptk_triangle* triangles, uint64_t num_triangles,
+                 ptk_kd_info* info, ptk_kd_node* nodes, uint64_t nodes_cap,
+                 uint32_t* prims, uint64_t prims_cap);
+
+/* ---- closest hit for caller-supplied rays (parity entry) -----------------
+ * scene::cast_ray (scene.cpp:355-399) for n rays.  SoA device arrays:
+ * origins/directions are 3 arrays of n floats each laid out [x0..xn-1|y..|z..].
+ * Outputs (any may be NULL): node = index in scene.nodes or -1; prim = index in
+ * the mesh's triangle list or -1 (sphere / miss); t = length(pos_world-origin)
+ * (scene.cpp:383 before squaring); (u,v) = (bar.y, bar.z) of
+ * triangle::baricentric (scene.cpp:78-89) for triangles, raycast_result::uv
+ * for spheres (scene.cpp:434-437); position/normal/uv = raycast_result in world
+ * space (3n,3n,2n floats SoA). */
+int ptk_intersect_batch_dev(ptk_ctx* ctx, uint64_t n,
+                            const float* origins_dev, const float* directions_dev,
+                            int32_t* node_dev, int32_t* prim_dev,
+                            float* t_dev, float* u_dev, float* v_dev,
+                            float* position_dev, float* normal_dev, float* uv_dev);
+/* Same with host pointers (copies in and out, synchronises). */
+int ptk_intersect_batch(ptk_ctx* ctx, uint64_t n,
+                        const float* origins, const float* directions,
+                        int32_t* node, int32_t* prim, float* t, float* u, float* v,
+                        float* position, float* normal, float* uv);
+
+/* ---- render loop ---------------------------------------------------------
+ * ptk_render_begin: the per-run set-up of the driver lambda,
+ * abstract_pathtracer.cpp:18-25 (camera basis, h2 = atan(fov_y/2), w2).
+ * max_paths_per_launch bounds the ray-queue allocation (0 = default 1<<24). */
+int ptk_render_begin(ptk_ctx* ctx, uint32_t width, uint32_t height, float fov_y,
+                     uint64_t max_paths_per_launch);
+
+/* The three hot loops of abstract_pathtracer.cpp:63-86 + pathtracer::trace
+ * (pathtracer.cpp:14-69): for every pixel in [pixel_begin, pixel_begin+pixel_count)
+ * (row-major index y*width+x, row 0 = top) trace the samples with global sample
+ * indices [sample_begin, sample_begin+sample_count) and write (accumulate=0) or
+ * add (accumulate=1) the SUM of their radiance to sum_rgb_dev[pixel*3+c]
+ * (width*height*3 floats).  Random numbers are a pure function of
+ * (seed, pixel, global sample index, dimension), so any split of the sample or
+ * pixel range over calls / GPUs produces the same set of samples. */
+int ptk_render_samples_dev(ptk_ctx* ctx, uint64_t seed,
+                           uint64_t pixel_begin, uint64_t pixel_count,
+                           uint64_t sample_begin, uint32_t sample_count,
+                           float* sum_rgb_dev, int accumulate);
+
+/* abstract_pathtracer.cpp:66,88-90: image = mix(sum/spi, image, it/float(it+1)). */
+int ptk_resolve_iteration_dev(ptk_ctx* ctx, const float* sum_rgb_dev, float* image_rgb_dev,
+                              uint64_t samples_per_iteration, uint64_t iteration);
+
+/* Convenience for single-GPU hosts: runs `iterations` full iterations
+ * (abstract_pathtracer.cpp:38-112, without events) into a host image. */
+int ptk_render_image(ptk_ctx* ctx, uint64_t seed, uint64_t iterations,
+                     uint32_t samples_per_iteration, float* image_rgb);
+
+/* CLI tone map + gamma + 8-bit pack, CLI/main.cpp:85-104.
+ * rgba8_dev: width*height uint32, r | g<<8 | b<<16 | 255<<24. */
+int ptk_tonemap_dev(ptk_ctx* ctx, const float* image_rgb_dev, uint32_t* rgba8_dev,
+                    uint64_t num_pixels);
+
+/* Device ray / path counters since the last reset (synchronises). */
+int ptk_get_counters(ptk_ctx* ctx, ptk_counters* out);
+int ptk_reset_counters(ptk_ctx* ctx);
+
+/* Flattened KD-tree the context holds for mesh `mesh` (tests, diagnostics). */
+int ptk_scene_kd_info(ptk_ctx* ctx, uint32_t mesh, ptk_kd_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTK_H */

@@ -1,0 +1,146 @@
+"""ctypes mirror of include/ptk.h and the loader for libptk.so.
+
+The product path is the HIP library: if libptk.so is missing this module raises —
+there is no CPU fallback (the CPU oracle under oracle/ is test infrastructure and
+is never imported from here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptk.so")
+
+PTK_OK = 0
+PTK_ERR_INVALID, PTK_ERR_HIP, PTK_ERR_STATE, PTK_ERR_NOMEM = 1, 2, 3, 4
+PTK_MAX_DEPTH = 5
+PTK_SAMPLER_COLOR, PTK_SAMPLER_IMAGE = 0, 1
+PTK_MODE_LINEAR, PTK_MODE_NEAREST = 0, 1
+PTK_SHAPE_SPHERE, PTK_SHAPE_MESH = 0, 1
+PTK_BACKGROUND_COLOR, PTK_BACKGROUND_EQUIRECT = 0, 1
+
+
+class Vertex(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("normal", C.c_float * 3), ("uv", C.c_float * 2)]
+
+
+class Triangle(C.Structure):
+    _fields_ = [("v", Vertex * 3)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("triangles", C.c_void_p), ("num_triangles", C.c_uint64)]
+
+
+class TextureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.c_void_p)]
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("color", C.c_float * 3), ("texture", C.c_uint32), ("mode", C.c_uint32)]
+
+
+class NodeDesc(C.Structure):
+    _fields_ = [
+        ("transform", C.c_float * 16),
+        ("inv_transform", C.c_float * 16),
+        ("normal_transform", C.c_float * 16),
+        ("shape_kind", C.c_uint32),
+        ("mesh", C.c_uint32),
+        ("albedo", C.c_uint32),
+        ("emission", C.c_uint32),
+        ("roughness", C.c_uint32),
+        ("metallic", C.c_uint32),
+    ]
+
+
+class BackgroundDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("color", C.c_float * 3), ("texture", C.c_uint32), ("mode", C.c_uint32)]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("direction", C.c_float * 3)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("nodes", C.c_void_p),
+        ("num_nodes", C.c_uint32),
+        ("meshes", C.c_void_p),
+        ("num_meshes", C.c_uint32),
+        ("samplers", C.c_void_p),
+        ("num_samplers", C.c_uint32),
+        ("textures", C.c_void_p),
+        ("num_textures", C.c_uint32),
+        ("background", BackgroundDesc),
+        ("camera", CameraDesc),
+    ]
+
+
+class KdNode(C.Structure):
+    _fields_ = [
+        ("bmin", C.c_float * 3),
+        ("bmax", C.c_float * 3),
+        ("skip", C.c_uint32),
+        ("first_prim", C.c_uint32),
+        ("num_prims", C.c_uint32),
+        ("depth", C.c_uint32),
+    ]
+
+
+class KdInfo(C.Structure):
+    _fields_ = [
+        ("num_nodes", C.c_uint32),
+        ("num_leaves", C.c_uint32),
+        ("num_leaf_prims", C.c_uint64),
+        ("max_depth", C.c_uint32),
+        ("bmin", C.c_float * 3),
+        ("bmax", C.c_float * 3),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64)]
+
+
+# name -> (restype, argtypes); every symbol include/ptk.h declares.
+SYMBOLS = {
+    "ptk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ptk_ctx_destroy": (None, [C.c_void_p]),
+    "ptk_last_error": (C.c_char_p, [C.c_void_p]),
+    "ptk_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ptk_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "ptk_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "ptk_scene_set_camera": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc)]),
+    "ptk_kd_build": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(KdInfo), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "ptk_intersect_batch_dev": (C.c_int, [C.c_void_p, C.c_uint64] + [C.c_void_p] * 10),
+    "ptk_intersect_batch": (C.c_int, [C.c_void_p, C.c_uint64] + [C.c_void_p] * 10),
+    "ptk_render_begin": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64]),
+    "ptk_render_samples_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int]),
+    "ptk_resolve_iteration_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "ptk_render_image": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "ptk_tonemap_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ptk_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "ptk_reset_counters": (C.c_int, [C.c_void_p]),
+    "ptk_scene_kd_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(KdInfo)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libptk.so (once). Raises RuntimeError if the HIP extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

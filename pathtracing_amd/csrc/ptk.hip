@@ -1,0 +1,872 @@
+// ptk.hip — gfx950 kernels and the C ABI of include/ptk.h.
+//
+// Pipeline (wavefront path tracing; reference loop: abstract_pathtracer.cpp:63-90
+// + pathtracer.cpp:14-69, paths relative to /root/reference/src/Pathtracing):
+//
+//   k_bounce<true>   bounce 0: generate the jittered primary ray of every
+//                    (pixel, sample) of the chunk, cast it, shade, emit the next ray
+//   k_bounce<false>  bounces 1..4: read the surviving rays of a 256-slot queue
+//                    segment, cast, shade, re-compact survivors inside the segment
+//   k_accumulate     per-pixel sum of the chunk's per-sample radiance
+//   k_tally          device path / ray counters
+//
+// Ray queue: SoA float arrays (origin, direction, throughput, radiance, path id),
+// 256-slot segments, one workgroup per segment.  Survivors of a bounce are packed to
+// the front of their own segment with wave64 ballot + mbcnt prefix and a 4-entry LDS
+// scan across the workgroup's waves, in place: no global atomics, no ping-pong
+// buffer, deterministic slot order.  A path that ends (miss, depth 5, zero
+// throughput) writes its radiance once to sample_L[path id].
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ptk_device.h"
+
+void ptk_kd_build_vectors(const ptk_triangle* triangles, uint64_t num_triangles, ptk_kd_info* info,
+                          std::vector<ptk_kd_node>& nodes, std::vector<uint32_t>& prims);
+
+using namespace ptk;
+
+namespace {
+
+constexpr int kBlock = 256;          // one queue segment = one workgroup = 4 waves
+constexpr int kStateFields = 13;     // o(3) d(3) T(3) L(3) path id
+constexpr uint64_t kDefaultMaxPaths = 1ull << 24;
+
+// ------------------------------------------------------------------ kernels
+
+__global__ __launch_bounds__(kBlock) void k_intersect_batch(const DScene S, uint64_t n, const float* __restrict__ o,
+                                                            const float* __restrict__ d, int32_t* __restrict__ node,
+                                                            int32_t* __restrict__ prim, float* __restrict__ t,
+                                                            float* __restrict__ u, float* __restrict__ v,
+                                                            float* __restrict__ position, float* __restrict__ normal,
+                                                            float* __restrict__ uv)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool on = i < n;
+    const uint64_t j = on ? i : 0;
+    const V3 ro = mk(o[j], o[n + j], o[2 * n + j]);
+    const V3 rd = mk(d[j], d[n + j], d[2 * n + j]);
+    Hit h;
+    intersect_scene(S, ro, rd, on, h);
+    if (!on) return;
+    V3 nw = mk(0.0f, 0.0f, 0.0f);
+    float uvx = 0.0f, uvy = 0.0f, uu = 0.0f, vv = 0.0f;
+    int prim_id = -1;
+    const bool hit = h.node >= 0;
+    if (hit) hit_attributes(S, h, nw, uvx, uvy, prim_id, uu, vv);
+    if (node) node[i] = h.node;
+    if (prim) prim[i] = prim_id;
+    if (t) t[i] = hit ? sqrtf(h.d0) : 0.0f;
+    if (u) u[i] = uu;
+    if (v) v[i] = vv;
+    if (position) {
+        position[i] = hit ? h.pw.x : 0.0f;
+        position[n + i] = hit ? h.pw.y : 0.0f;
+        position[2 * n + i] = hit ? h.pw.z : 0.0f;
+    }
+    if (normal) {
+        normal[i] = nw.x;
+        normal[n + i] = nw.y;
+        normal[2 * n + i] = nw.z;
+    }
+    if (uv) {
+        uv[i] = uvx;
+        uv[n + i] = uvy;
+    }
+}
+
+struct BounceArgs {
+    float* state;        // kStateFields arrays of `cap` floats
+    float* sample_L;     // 3 arrays of `cap` floats, indexed by path id
+    uint32_t* seg_count; // [PTK_MAX_DEPTH][num_segments]; row b = live rays entering bounce b
+    uint64_t cap;
+    uint32_t num_segments;
+    uint32_t n_paths;       // paths in this chunk (<= cap)
+    uint32_t samples;       // samples per pixel in this chunk
+    uint64_t pixel_begin;   // first pixel of the chunk
+    uint64_t sample_begin;  // first global sample index of the chunk
+    uint64_t seed;
+    uint32_t bounce;
+};
+
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V, const BounceArgs A)
+{
+    __shared__ uint32_t wave_count[kBlock / 64];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t slot = seg * kBlock + tid;
+    uint32_t cnt;
+    if (FIRST) {
+        const uint32_t base = seg * kBlock;
+        cnt = (A.n_paths > base) ? min((uint32_t)kBlock, A.n_paths - base) : 0u;
+    } else {
+        cnt = A.seg_count[(size_t)A.bounce * A.num_segments + seg];
+    }
+    if (cnt == 0u) {
+        if (tid == 0 && A.bounce + 1 < PTK_MAX_DEPTH) A.seg_count[(size_t)(A.bounce + 1) * A.num_segments + seg] = 0u;
+        return;
+    }
+    const bool on = tid < cnt;
+    float* __restrict__ st = A.state;
+    const uint64_t cap = A.cap;
+
+    V3 o, d, T, L;
+    uint32_t path;
+    uint32_t pixel;
+    uint64_t sample;
+    if (FIRST) {
+        path = slot;
+        const uint32_t pl = path / A.samples;
+        const uint32_t s = path - pl * A.samples;
+        pixel = (uint32_t)(A.pixel_begin + pl);
+        sample = A.sample_begin + s;
+        float u1, u2;
+        rng_pair(A.seed, pixel, sample, 0u, u1, u2);
+        o = mk(S.cam_x, S.cam_y, S.cam_z);
+        d = primary_dir(V, pixel % V.width, pixel / V.width, u1, u2);
+        T = mk(1.0f, 1.0f, 1.0f);
+        L = mk(0.0f, 0.0f, 0.0f);
+    } else {
+        const uint32_t rs = on ? slot : seg * kBlock;
+        o = mk(st[0 * cap + rs], st[1 * cap + rs], st[2 * cap + rs]);
+        d = mk(st[3 * cap + rs], st[4 * cap + rs], st[5 * cap + rs]);
+        T = mk(st[6 * cap + rs], st[7 * cap + rs], st[8 * cap + rs]);
+        L = mk(st[9 * cap + rs], st[10 * cap + rs], st[11 * cap + rs]);
+        path = __float_as_uint(st[12 * cap + rs]);
+        const uint32_t pl = path / A.samples;
+        const uint32_t s = path - pl * A.samples;
+        pixel = (uint32_t)(A.pixel_begin + pl);
+        sample = A.sample_begin + s;
+    }
+
+    Hit h;
+    intersect_scene(S, o, d, on, h);
+
+    bool alive = false;
+    if (on) {
+        if (h.node < 0) {
+            // pathtracer.cpp:67: miss -> background
+            L = L + mulv(T, background_sample(S, d));
+        } else {
+            V3 n;
+            float uvx, uvy, uu, vv;
+            int prim_id;
+            hit_attributes(S, h, n, uvx, uvy, prim_id, uu, vv);
+            const DNode* __restrict__ nd = S.nodes + h.node;
+            // pathtracer.cpp:34-37
+            const V3 albedo = sampler_sample(S, nd->albedo, uvx, uvy);
+            const V3 emission = sampler_sample(S, nd->emission, uvx, uvy);
+            const float roughness = sampler_sample(S, nd->roughness, uvx, uvy).x;
+            const float metallic = sampler_sample(S, nd->metallic, uvx, uvy).x;
+            L = L + mulv(T, emission);
+            if (A.bounce + 1 < PTK_MAX_DEPTH) {
+                float u1, u2;
+                rng_pair(A.seed, pixel, sample, 1u + A.bounce, u1, u2);
+                // pathtracer.cpp:40-54
+                const V3 hemi = hemisphere_dir(n, u1, u2);
+                const V3 refl = d - n * dot(n, d) * 2.0f;
+                const V3 dir = normalize(mix(refl, hemi, roughness));
+                const float dn = dot(dir, n);
+                const float cos_theta = (0.0f < dn) ? dn : 0.0f;
+                // pathtracer.cpp:60 in throughput form
+                const V3 m = mix(albedo, mk(1.0f, 1.0f, 1.0f), metallic);
+                T = mulv(T, m) * cos_theta * 2.0f;
+                o = h.pw + dir * PTK_EPSILON;
+                d = dir;
+                alive = (T.x != 0.0f) || (T.y != 0.0f) || (T.z != 0.0f);
+            }
+        }
+        if (!alive) {
+            float* __restrict__ sl = A.sample_L;
+            sl[0 * cap + path] = L.x;
+            sl[1 * cap + path] = L.y;
+            sl[2 * cap + path] = L.z;
+        }
+    }
+
+    if (A.bounce + 1 >= PTK_MAX_DEPTH) return;
+
+    // In-segment compaction: wave64 ballot + mbcnt prefix, then a scan over the
+    // workgroup's four wave counts in LDS.
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
+    const uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t wave = tid >> 6;
+    if ((tid & 63u) == 0u) wave_count[wave] = (uint32_t)__popcll(mask);
+    __syncthreads(); // also orders every wave's state reads before the in-place writes
+    uint32_t offset = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        const uint32_t c = wave_count[w];
+        offset += (w < wave) ? c : 0u;
+        total += c;
+    }
+    if (tid == 0) A.seg_count[(size_t)(A.bounce + 1) * A.num_segments + seg] = total;
+    if (alive) {
+        const uint32_t ws = seg * kBlock + offset + lane_rank;
+        st[0 * cap + ws] = o.x;  st[1 * cap + ws] = o.y;  st[2 * cap + ws] = o.z;
+        st[3 * cap + ws] = d.x;  st[4 * cap + ws] = d.y;  st[5 * cap + ws] = d.z;
+        st[6 * cap + ws] = T.x;  st[7 * cap + ws] = T.y;  st[8 * cap + ws] = T.z;
+        st[9 * cap + ws] = L.x;  st[10 * cap + ws] = L.y; st[11 * cap + ws] = L.z;
+        st[12 * cap + ws] = __uint_as_float(path);
+    }
+}
+
+// abstract_pathtracer.cpp:70,85: color = sum over the pixel's samples.  One wave per
+// pixel: lane l adds samples l, l+64, ... in order, then a fixed butterfly combines
+// the 64 partial sums, so the result is deterministic.
+__global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__ sample_L, uint64_t cap,
+                                                       uint32_t num_pixels, uint32_t samples, uint64_t pixel_begin,
+                                                       float* __restrict__ sum_rgb, int accumulate)
+{
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (wave >= num_pixels) return;
+    const uint64_t base = (uint64_t)wave * samples;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t s = lane; s < samples; s += 64u) {
+        r += sample_L[0 * cap + base + s];
+        g += sample_L[1 * cap + base + s];
+        b += sample_L[2 * cap + base + s];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        r += __shfl_xor(r, off);
+        g += __shfl_xor(g, off);
+        b += __shfl_xor(b, off);
+    }
+    if (lane == 0) {
+        float* o = sum_rgb + (pixel_begin + wave) * 3;
+        if (accumulate) {
+            o[0] += r; o[1] += g; o[2] += b;
+        } else {
+            o[0] = r; o[1] = g; o[2] = b;
+        }
+    }
+}
+
+// rays of a chunk = sum over bounces of the live-ray counts; one atomic per block.
+__global__ __launch_bounds__(kBlock) void k_tally(const uint32_t* __restrict__ seg_count, uint32_t entries,
+                                                  uint32_t n_paths, unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned long long part[kBlock / 64];
+    unsigned long long acc = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < entries; i += gridDim.x * kBlock) acc += seg_count[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < kBlock / 64; ++w) tot += part[w];
+        if (blockIdx.x == 0) {
+            tot += n_paths; // bounce 0 casts one ray per path
+            atomicAdd(&counters[0], (unsigned long long)n_paths);
+        }
+        atomicAdd(&counters[1], tot);
+    }
+}
+
+// abstract_pathtracer.cpp:66,88-90
+__global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ sum_rgb, float* __restrict__ image,
+                                                    uint64_t n, float spi, float t)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float c = sum_rgb[i] / spi;
+    image[i] = c * (1.0f - t) + image[i] * t;
+}
+
+// CLI/main.cpp:91-103
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float* __restrict__ image, uint32_t* __restrict__ rgba,
+                                                    uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t px = 255u << 24;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = 1.0f - expf(-image[i * 3 + c]);
+        v = powf(v, 1.0f / 2.2f);
+        px |= ((uint32_t)(v * 255) & 0xFFu) << (8 * c);
+    }
+    rgba[i] = px;
+}
+
+std::string g_create_error;
+
+} // namespace
+
+// ------------------------------------------------------------------ context
+
+struct ptk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene tables in HBM
+    std::vector<void*> allocs;      // scene allocations
+    DScene S{};
+    bool has_scene = false;
+    uint32_t num_meshes = 0, num_samplers = 0, num_textures = 0;
+    std::vector<ptk_kd_info> kd_infos;
+
+    // render state
+    float cam_dir[3] = { 0.0f, 0.0f, -1.0f }; // rt::camera::m_direction (scene.h:36)
+    DView V{};
+    bool has_view = false;
+    uint64_t cap = 0;
+    float* d_state = nullptr;
+    float* d_sample_L = nullptr;
+    uint32_t* d_seg_count = nullptr;
+    unsigned long long* d_counters = nullptr;
+};
+
+namespace {
+
+int fail(ptk_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define PTK_HIP(ctx, call)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail((ctx), PTK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+void free_scene(ptk_ctx* c)
+{
+    for (void* p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    c->has_scene = false;
+    c->kd_infos.clear();
+}
+
+void free_render(ptk_ctx* c)
+{
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_sample_L) (void)hipFree(c->d_sample_L);
+    if (c->d_seg_count) (void)hipFree(c->d_seg_count);
+    c->d_state = c->d_sample_L = nullptr;
+    c->d_seg_count = nullptr;
+    c->cap = 0;
+    c->has_view = false;
+}
+
+template <typename T>
+int upload(ptk_ctx* c, const std::vector<T>& host, const T** out)
+{
+    const size_t bytes = (host.empty() ? 1 : host.size()) * sizeof(T);
+    void* p = nullptr;
+    PTK_HIP(c, hipMalloc(&p, bytes));
+    c->allocs.push_back(p);
+    if (!host.empty()) PTK_HIP(c, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return PTK_OK;
+}
+
+struct HV3 {
+    float x, y, z;
+};
+inline HV3 hsub(HV3 a, HV3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline float hdot(HV3 a, HV3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline HV3 hcross(HV3 a, HV3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+inline HV3 hnormalize(HV3 a)
+{
+    const float s = 1.0f / std::sqrt(hdot(a, a));
+    return { a.x * s, a.y * s, a.z * s };
+}
+
+// triangle::update, scene.cpp:91-107 -> 64-B hit record
+void make_hit_record(const ptk_triangle& t, float4* q)
+{
+    const HV3 p0 = { t.v[0].position[0], t.v[0].position[1], t.v[0].position[2] };
+    const HV3 p1 = { t.v[1].position[0], t.v[1].position[1], t.v[1].position[2] };
+    const HV3 p2 = { t.v[2].position[0], t.v[2].position[1], t.v[2].position[2] };
+    const HV3 N = hnormalize(hcross(hsub(p1, p0), hsub(p2, p1)));
+    const HV3 e0 = hsub(p1, p0), e1 = hsub(p2, p0);
+    const float d00 = hdot(e0, e0), d01 = hdot(e0, e1), d11 = hdot(e1, e1);
+    const float inv_den = 1.0f / (d00 * d11 - d01 * d01);
+    q[0] = make_float4(p0.x, p0.y, p0.z, N.x);
+    q[1] = make_float4(N.y, N.z, e0.x, e0.y);
+    q[2] = make_float4(e0.z, e1.x, e1.y, e1.z);
+    q[3] = make_float4(d00, d01, d11, inv_den);
+}
+
+void make_shade_record(const ptk_triangle& t, float4* s)
+{
+    s[0] = make_float4(t.v[0].normal[0], t.v[0].normal[1], t.v[0].normal[2], t.v[1].normal[0]);
+    s[1] = make_float4(t.v[1].normal[1], t.v[1].normal[2], t.v[2].normal[0], t.v[2].normal[1]);
+    s[2] = make_float4(t.v[2].normal[2], t.v[0].uv[0], t.v[0].uv[1], t.v[1].uv[0]);
+    s[3] = make_float4(t.v[1].uv[1], t.v[2].uv[0], t.v[2].uv[1], 0.0f);
+}
+
+int set_device(ptk_ctx* c)
+{
+    PTK_HIP(c, hipSetDevice(c->device));
+    return PTK_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ptk_ctx_create(int device, ptk_ctx** out)
+{
+    if (!out) return fail(nullptr, PTK_ERR_INVALID, "ptk_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return fail(nullptr, PTK_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return fail(nullptr, PTK_ERR_INVALID, "ptk_ctx_create: device " + std::to_string(device) + " out of range (" +
+                                                  std::to_string(count) + " visible)");
+    ptk_ctx* c = new ptk_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->own_stream)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->d_counters, 2 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long))) != hipSuccess) {
+        g_create_error = std::string("ptk_ctx_create: ") + hipGetErrorString(e);
+        delete c;
+        return PTK_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return PTK_OK;
+}
+
+void ptk_ctx_destroy(ptk_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_render(c);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* ptk_last_error(const ptk_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int ptk_ctx_set_stream(ptk_ctx* c, void* hip_stream)
+{
+    if (!c) return PTK_ERR_INVALID;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return PTK_OK;
+}
+
+int ptk_ctx_synchronize(ptk_ctx* c)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
+{
+    if (!c || !sc) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    // Validate every index the kernels will follow before anything reaches the GPU.
+    if ((sc->num_nodes && !sc->nodes) || (sc->num_meshes && !sc->meshes) || (sc->num_samplers && !sc->samplers) ||
+        (sc->num_textures && !sc->textures))
+        return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: NULL table with non-zero count");
+    for (uint32_t i = 0; i < sc->num_textures; ++i)
+        if (!sc->textures[i].rgb || sc->textures[i].width == 0 || sc->textures[i].height == 0)
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: texture " + std::to_string(i) + " is empty");
+    for (uint32_t i = 0; i < sc->num_samplers; ++i) {
+        const ptk_sampler_desc& s = sc->samplers[i];
+        if (s.kind != PTK_SAMPLER_COLOR && s.kind != PTK_SAMPLER_IMAGE)
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: sampler " + std::to_string(i) + " has unknown kind");
+        if (s.kind == PTK_SAMPLER_IMAGE && (s.texture >= sc->num_textures || s.mode > PTK_MODE_NEAREST))
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: sampler " + std::to_string(i) + " texture/mode out of range");
+    }
+    for (uint32_t i = 0; i < sc->num_nodes; ++i) {
+        const ptk_node_desc& n = sc->nodes[i];
+        if (n.shape_kind != PTK_SHAPE_SPHERE && n.shape_kind != PTK_SHAPE_MESH)
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: node " + std::to_string(i) + " has no shape");
+        if (n.shape_kind == PTK_SHAPE_MESH && n.mesh >= sc->num_meshes)
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: node " + std::to_string(i) + " mesh index out of range");
+        if (n.albedo >= sc->num_samplers || n.emission >= sc->num_samplers || n.roughness >= sc->num_samplers ||
+            n.metallic >= sc->num_samplers)
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: node " + std::to_string(i) + " sampler index out of range");
+    }
+    if (sc->background.kind != PTK_BACKGROUND_COLOR && sc->background.kind != PTK_BACKGROUND_EQUIRECT)
+        return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: unknown background kind");
+    if (sc->background.kind == PTK_BACKGROUND_EQUIRECT &&
+        (sc->background.texture >= sc->num_textures || sc->background.mode > PTK_MODE_NEAREST))
+        return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: background texture/mode out of range");
+    for (uint32_t i = 0; i < sc->num_meshes; ++i)
+        if (sc->meshes[i].num_triangles && !sc->meshes[i].triangles)
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: mesh " + std::to_string(i) + " has NULL triangles");
+
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+
+    // Host flattening: KD build per mesh (reference topology), leaf-ordered hit
+    // records, original-order shading records.
+    std::vector<DMesh> meshes(sc->num_meshes);
+    std::vector<DKdNode> kd;
+    std::vector<float4> tri_hit, tri_shade;
+    std::vector<uint32_t> leaf_prim;
+    c->kd_infos.resize(sc->num_meshes);
+    for (uint32_t m = 0; m < sc->num_meshes; ++m) {
+        const ptk_mesh_desc& md = sc->meshes[m];
+        std::vector<ptk_kd_node> nodes;
+        std::vector<uint32_t> prims;
+        ptk_kd_build_vectors(md.triangles, md.num_triangles, &c->kd_infos[m], nodes, prims);
+        if (kd.size() + nodes.size() > 0xFFFFFFF0ull || leaf_prim.size() + prims.size() > 0x7FFFFFF0ull)
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: scene exceeds 32-bit table indices");
+        DMesh& dm = meshes[m];
+        dm.kd_base = (uint32_t)kd.size();
+        dm.kd_count = (uint32_t)nodes.size();
+        dm.leaf_base = (uint32_t)leaf_prim.size();
+        dm.shade_base = (uint32_t)(tri_shade.size() / 4);
+        for (const ptk_kd_node& n : nodes) {
+            DKdNode k;
+            std::memcpy(k.bmin, n.bmin, 12);
+            std::memcpy(k.bmax, n.bmax, 12);
+            if (n.num_prims) {
+                k.a = n.first_prim;
+                k.b = n.num_prims;
+            } else {
+                k.a = n.skip;
+                k.b = 0;
+            }
+            kd.push_back(k);
+        }
+        std::vector<float4> rec((size_t)md.num_triangles * 4);
+        for (uint64_t t = 0; t < md.num_triangles; ++t) make_hit_record(md.triangles[t], &rec[t * 4]);
+        const size_t h0 = tri_hit.size();
+        tri_hit.resize(h0 + prims.size() * 4);
+        for (size_t k = 0; k < prims.size(); ++k) std::memcpy(&tri_hit[h0 + k * 4], &rec[(size_t)prims[k] * 4], 64);
+        leaf_prim.insert(leaf_prim.end(), prims.begin(), prims.end());
+        const size_t s0 = tri_shade.size();
+        tri_shade.resize(s0 + (size_t)md.num_triangles * 4);
+        for (uint64_t t = 0; t < md.num_triangles; ++t) make_shade_record(md.triangles[t], &tri_shade[s0 + t * 4]);
+    }
+
+    std::vector<DNode> nodes(sc->num_nodes);
+    for (uint32_t i = 0; i < sc->num_nodes; ++i) {
+        const ptk_node_desc& n = sc->nodes[i];
+        DNode& d = nodes[i];
+        std::memset(&d, 0, sizeof(d));
+        std::memcpy(d.inv, n.inv_transform, 64);
+        std::memcpy(d.xf, n.transform, 64);
+        std::memcpy(d.nrm, n.normal_transform, 64);
+        d.kind = n.shape_kind;
+        d.mesh = n.shape_kind == PTK_SHAPE_MESH ? n.mesh : 0u;
+        d.albedo = n.albedo;
+        d.emission = n.emission;
+        d.roughness = n.roughness;
+        d.metallic = n.metallic;
+    }
+    std::vector<DSampler> samplers(sc->num_samplers);
+    for (uint32_t i = 0; i < sc->num_samplers; ++i) {
+        const ptk_sampler_desc& s = sc->samplers[i];
+        samplers[i] = DSampler{ s.kind, s.color[0], s.color[1], s.color[2], s.kind == PTK_SAMPLER_IMAGE ? s.texture : 0u,
+                                s.mode, 0u, 0u };
+    }
+    std::vector<DTexture> textures(sc->num_textures);
+    for (uint32_t i = 0; i < sc->num_textures; ++i) {
+        const ptk_texture_desc& t = sc->textures[i];
+        const size_t bytes = (size_t)t.width * t.height * 3 * sizeof(float);
+        void* p = nullptr;
+        PTK_HIP(c, hipMalloc(&p, bytes));
+        c->allocs.push_back(p);
+        PTK_HIP(c, hipMemcpy(p, t.rgb, bytes, hipMemcpyHostToDevice));
+        textures[i] = DTexture{ static_cast<const float*>(p), t.width, t.height };
+    }
+
+    DScene S{};
+    if (int r = upload(c, nodes, &S.nodes)) return r;
+    if (int r = upload(c, meshes, &S.meshes)) return r;
+    if (int r = upload(c, kd, &S.kd)) return r;
+    if (int r = upload(c, tri_hit, &S.tri_hit)) return r;
+    if (int r = upload(c, leaf_prim, &S.leaf_prim)) return r;
+    if (int r = upload(c, tri_shade, &S.tri_shade)) return r;
+    if (int r = upload(c, samplers, &S.samplers)) return r;
+    if (int r = upload(c, textures, &S.textures)) return r;
+    S.num_nodes = sc->num_nodes;
+    S.bg_kind = sc->background.kind;
+    S.bg_r = sc->background.color[0];
+    S.bg_g = sc->background.color[1];
+    S.bg_b = sc->background.color[2];
+    S.bg_texture = sc->background.kind == PTK_BACKGROUND_EQUIRECT ? sc->background.texture : 0u;
+    S.bg_mode = sc->background.mode;
+    S.cam_x = sc->camera.position[0];
+    S.cam_y = sc->camera.position[1];
+    S.cam_z = sc->camera.position[2];
+    c->S = S;
+    c->num_meshes = sc->num_meshes;
+    c->num_samplers = sc->num_samplers;
+    c->num_textures = sc->num_textures;
+    c->has_scene = true;
+    // camera direction feeds the view basis built by ptk_render_begin
+    std::memcpy(c->cam_dir, sc->camera.direction, sizeof(c->cam_dir));
+    c->has_view = false;
+    return PTK_OK;
+}
+
+int ptk_scene_set_camera(ptk_ctx* c, const ptk_camera_desc* cam)
+{
+    if (!c || !cam) return PTK_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PTK_ERR_STATE, "ptk_scene_set_camera: no scene uploaded");
+    c->S.cam_x = cam->position[0];
+    c->S.cam_y = cam->position[1];
+    c->S.cam_z = cam->position[2];
+    std::memcpy(c->cam_dir, cam->direction, sizeof(c->cam_dir));
+    c->has_view = false; // ptk_render_begin must be called again
+    return PTK_OK;
+}
+
+int ptk_scene_kd_info(ptk_ctx* c, uint32_t mesh, ptk_kd_info* info)
+{
+    if (!c || !info) return PTK_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PTK_ERR_STATE, "ptk_scene_kd_info: no scene uploaded");
+    if (mesh >= c->kd_infos.size()) return fail(c, PTK_ERR_INVALID, "ptk_scene_kd_info: mesh index out of range");
+    *info = c->kd_infos[mesh];
+    return PTK_OK;
+}
+
+int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float* d, int32_t* node, int32_t* prim,
+                            float* t, float* u, float* v, float* position, float* normal, float* uv)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PTK_ERR_STATE, "ptk_intersect_batch: no scene uploaded");
+    if (n == 0) return PTK_OK;
+    if (!o || !d) return fail(c, PTK_ERR_INVALID, "ptk_intersect_batch: NULL ray arrays");
+    if (n > 0x7FFFFFFFull * kBlock) return fail(c, PTK_ERR_INVALID, "ptk_intersect_batch: batch too large");
+    if (int r = set_device(c)) return r;
+    const uint32_t blocks = (uint32_t)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_intersect_batch, dim3(blocks), dim3(kBlock), 0, c->stream, c->S, n, o, d, node, prim, t, u, v,
+                       position, normal, uv);
+    PTK_HIP(c, hipGetLastError());
+    return PTK_OK;
+}
+
+int ptk_intersect_batch(ptk_ctx* c, uint64_t n, const float* o, const float* d, int32_t* node, int32_t* prim, float* t,
+                        float* u, float* v, float* position, float* normal, float* uv)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PTK_ERR_STATE, "ptk_intersect_batch: no scene uploaded");
+    if (n == 0) return PTK_OK;
+    if (!o || !d) return fail(c, PTK_ERR_INVALID, "ptk_intersect_batch: NULL ray arrays");
+    if (int r = set_device(c)) return r;
+    // one staging allocation: o(3n) d(3n) node prim t u v pos(3n) nrm(3n) uv(2n) = 19n words
+    float* buf = nullptr;
+    PTK_HIP(c, hipMalloc((void**)&buf, (size_t)n * 19 * sizeof(float)));
+    float* d_o = buf;
+    float* d_d = buf + 3 * n;
+    int32_t* d_node = reinterpret_cast<int32_t*>(buf + 6 * n);
+    int32_t* d_prim = reinterpret_cast<int32_t*>(buf + 7 * n);
+    float* d_t = buf + 8 * n;
+    float* d_u = buf + 9 * n;
+    float* d_v = buf + 10 * n;
+    float* d_pos = buf + 11 * n;
+    float* d_nrm = buf + 14 * n;
+    float* d_uv = buf + 17 * n;
+    int rc = PTK_OK;
+    hipError_t e;
+    if ((e = hipMemcpyAsync(d_o, o, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_d, d, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream)) != hipSuccess) {
+        rc = fail(c, PTK_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
+    if (rc == PTK_OK) rc = ptk_intersect_batch_dev(c, n, d_o, d_d, d_node, d_prim, d_t, d_u, d_v, d_pos, d_nrm, d_uv);
+    auto back = [&](void* dst, const void* src, size_t words) {
+        if (rc == PTK_OK && dst) {
+            e = hipMemcpyAsync(dst, src, words * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(c, PTK_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+        }
+    };
+    back(node, d_node, n);
+    back(prim, d_prim, n);
+    back(t, d_t, n);
+    back(u, d_u, n);
+    back(v, d_v, n);
+    back(position, d_pos, 3 * n);
+    back(normal, d_nrm, 3 * n);
+    back(uv, d_uv, 2 * n);
+    e = hipStreamSynchronize(c->stream);
+    if (rc == PTK_OK && e != hipSuccess) rc = fail(c, PTK_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    (void)hipFree(buf);
+    return rc;
+}
+
+int ptk_render_begin(ptk_ctx* c, uint32_t width, uint32_t height, float fov_y, uint64_t max_paths)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PTK_ERR_STATE, "ptk_render_begin: no scene uploaded");
+    if (width == 0 || height == 0) return fail(c, PTK_ERR_INVALID, "ptk_render_begin: empty viewport");
+    if ((uint64_t)width * height > 0xFFFFFFFFull) return fail(c, PTK_ERR_INVALID, "ptk_render_begin: viewport too large");
+    if (int r = set_device(c)) return r;
+    if (max_paths == 0) max_paths = kDefaultMaxPaths;
+    if (max_paths > 0x7FFFFF00ull) max_paths = 0x7FFFFF00ull;
+    const uint64_t cap = (max_paths + kBlock - 1) / kBlock * kBlock;
+
+    // abstract_pathtracer.cpp:20-25 (host fp32, same operand order as the oracle)
+    const HV3 fwd = hnormalize({ c->cam_dir[0], c->cam_dir[1], c->cam_dir[2] });
+    const HV3 right = hnormalize(hcross(fwd, { 0.0f, 1.0f, 0.0f }));
+    const HV3 up = hcross(right, fwd);
+    DView V{};
+    V.fx = fwd.x; V.fy = fwd.y; V.fz = fwd.z;
+    V.rx = right.x; V.ry = right.y; V.rz = right.z;
+    V.ux = up.x; V.uy = up.y; V.uz = up.z;
+    V.h2 = std::atan(fov_y / 2.0f);
+    V.w2 = V.h2 * (float)width / (float)height;
+    V.width = width;
+    V.height = height;
+
+    if (cap != c->cap) {
+        PTK_HIP(c, hipStreamSynchronize(c->stream));
+        free_render(c);
+        PTK_HIP(c, hipMalloc((void**)&c->d_state, cap * kStateFields * sizeof(float)));
+        PTK_HIP(c, hipMalloc((void**)&c->d_sample_L, cap * 3 * sizeof(float)));
+        PTK_HIP(c, hipMalloc((void**)&c->d_seg_count, (cap / kBlock) * PTK_MAX_DEPTH * sizeof(uint32_t)));
+        c->cap = cap;
+    }
+    c->V = V;
+    c->has_view = true;
+    return PTK_OK;
+}
+
+int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint64_t pixel_count, uint64_t sample_begin,
+                           uint32_t sample_count, float* sum_rgb, int accumulate)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene || !c->has_view) return fail(c, PTK_ERR_STATE, "ptk_render_samples: call ptk_render_begin first");
+    if (!sum_rgb) return fail(c, PTK_ERR_INVALID, "ptk_render_samples: NULL sum buffer");
+    const uint64_t num_pixels = (uint64_t)c->V.width * c->V.height;
+    if (pixel_begin > num_pixels || pixel_count > num_pixels - pixel_begin)
+        return fail(c, PTK_ERR_INVALID, "ptk_render_samples: pixel range outside the viewport");
+    if (pixel_count == 0) return PTK_OK;
+    if (int r = set_device(c)) return r;
+    if (sample_count == 0) {
+        if (!accumulate) PTK_HIP(c, hipMemsetAsync(sum_rgb + pixel_begin * 3, 0, pixel_count * 3 * sizeof(float), c->stream));
+        return PTK_OK;
+    }
+    const uint64_t cap = c->cap;
+    const uint32_t s_chunk = (uint32_t)((uint64_t)sample_count < cap ? sample_count : cap);
+    const uint64_t p_chunk = cap / s_chunk;
+    for (uint32_t s0 = 0; s0 < sample_count; s0 += s_chunk) {
+        const uint32_t ns = (sample_count - s0 < s_chunk) ? sample_count - s0 : s_chunk;
+        const int acc = (accumulate || s0 > 0) ? 1 : 0;
+        for (uint64_t p0 = 0; p0 < pixel_count; p0 += p_chunk) {
+            const uint64_t np = (pixel_count - p0 < p_chunk) ? pixel_count - p0 : p_chunk;
+            const uint64_t n_paths = np * ns; // <= cap < 2^31
+            BounceArgs A{};
+            A.state = c->d_state;
+            A.sample_L = c->d_sample_L;
+            A.seg_count = c->d_seg_count;
+            A.cap = cap;
+            A.num_segments = (uint32_t)((n_paths + kBlock - 1) / kBlock);
+            A.n_paths = (uint32_t)n_paths;
+            A.samples = ns;
+            A.pixel_begin = pixel_begin + p0;
+            A.sample_begin = sample_begin + s0;
+            A.seed = seed;
+            A.bounce = 0;
+            k_bounce<true><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+            for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) {
+                A.bounce = b;
+                k_bounce<false><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+            }
+            const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, c->d_sample_L, cap,
+                               (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
+            const uint32_t entries = A.num_segments * (PTK_MAX_DEPTH - 1);
+            const uint32_t tally_blocks = entries / (kBlock * 8) + 1 > 256u ? 256u : entries / (kBlock * 8) + 1;
+            hipLaunchKernelGGL(k_tally, dim3(tally_blocks), dim3(kBlock), 0, c->stream,
+                               c->d_seg_count + A.num_segments, entries, (uint32_t)n_paths, c->d_counters);
+            PTK_HIP(c, hipGetLastError());
+        }
+    }
+    return PTK_OK;
+}
+
+int ptk_resolve_iteration_dev(ptk_ctx* c, const float* sum_rgb, float* image_rgb, uint64_t spi, uint64_t iteration)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_view) return fail(c, PTK_ERR_STATE, "ptk_resolve_iteration: call ptk_render_begin first");
+    if (!sum_rgb || !image_rgb || spi == 0) return fail(c, PTK_ERR_INVALID, "ptk_resolve_iteration: bad arguments");
+    if (int r = set_device(c)) return r;
+    const uint64_t n = (uint64_t)c->V.width * c->V.height * 3;
+    const float t = (float)iteration / (float)(iteration + 1);
+    hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sum_rgb,
+                       image_rgb, n, (float)spi, t);
+    PTK_HIP(c, hipGetLastError());
+    return PTK_OK;
+}
+
+int ptk_render_image(ptk_ctx* c, uint64_t seed, uint64_t iterations, uint32_t spi, float* image_rgb)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene || !c->has_view) return fail(c, PTK_ERR_STATE, "ptk_render_image: call ptk_render_begin first");
+    if (!image_rgb || spi == 0) return fail(c, PTK_ERR_INVALID, "ptk_render_image: bad arguments");
+    if (int r = set_device(c)) return r;
+    const uint64_t np = (uint64_t)c->V.width * c->V.height;
+    float* buf = nullptr;
+    PTK_HIP(c, hipMalloc((void**)&buf, np * 6 * sizeof(float)));
+    float* d_sum = buf;
+    float* d_img = buf + np * 3;
+    int rc = PTK_OK;
+    hipError_t e = hipMemsetAsync(d_img, 0, np * 3 * sizeof(float), c->stream);
+    if (e != hipSuccess) rc = fail(c, PTK_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    for (uint64_t it = 0; it < iterations && rc == PTK_OK; ++it) {
+        rc = ptk_render_samples_dev(c, seed, 0, np, it * spi, spi, d_sum, 0);
+        if (rc == PTK_OK) rc = ptk_resolve_iteration_dev(c, d_sum, d_img, spi, it);
+    }
+    if (rc == PTK_OK) {
+        e = hipMemcpyAsync(image_rgb, d_img, np * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(c, PTK_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
+    e = hipStreamSynchronize(c->stream);
+    if (rc == PTK_OK && e != hipSuccess) rc = fail(c, PTK_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    (void)hipFree(buf);
+    return rc;
+}
+
+int ptk_tonemap_dev(ptk_ctx* c, const float* image_rgb, uint32_t* rgba8, uint64_t num_pixels)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!image_rgb || !rgba8) return fail(c, PTK_ERR_INVALID, "ptk_tonemap: NULL buffer");
+    if (num_pixels == 0) return PTK_OK;
+    if (int r = set_device(c)) return r;
+    hipLaunchKernelGGL(k_tonemap, dim3((uint32_t)((num_pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                       image_rgb, rgba8, num_pixels);
+    PTK_HIP(c, hipGetLastError());
+    return PTK_OK;
+}
+
+int ptk_get_counters(ptk_ctx* c, ptk_counters* out)
+{
+    if (!c || !out) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    unsigned long long h[2] = { 0, 0 };
+    PTK_HIP(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    out->paths = h[0];
+    out->rays = h[1];
+    return PTK_OK;
+}
+
+int ptk_reset_counters(ptk_ctx* c)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    PTK_HIP(c, hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+    return PTK_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,438 @@
+// ptk_device.h — device-side data layout and the intersect / shade functions
+// shared by every kernel in ptk.hip (gfx950 only).
+//
+// Arithmetic contract: every expression that feeds a hit DECISION is written in
+// the same operand order as the reference (file:line cited at each function,
+// relative to /root/reference/src/Pathtracing) with glm's published evaluation
+// order (see oracle/pt_oracle.c header), and the translation unit is built with
+// -ffp-contract=off and correctly rounded fp32 divide / sqrt, so node and
+// primitive ids replay the reference's x86-64 -O2 build bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptk.h"
+
+namespace ptk {
+
+// ---------------------------------------------------------------- HBM layout
+// Node table: one 256-B record per scene node.  Indexed by a wave-uniform loop
+// counter in intersect_scene, so hipcc fetches it through the scalar cache.
+struct alignas(16) DNode {
+    float inv[16]; // scene_node::m_inv_transform    (scene.h:289)
+    float xf[16];  // scene_node::m_transform        (scene.h:288)
+    float nrm[16]; // scene_node::m_normal_transform (scene.h:290)
+    uint32_t kind, mesh;
+    uint32_t albedo, emission, roughness, metallic;
+    uint32_t pad[10];
+};
+static_assert(sizeof(DNode) == 256, "DNode must be 256 B");
+
+// Flattened KD node, 32 B = two dwordx4 loads.
+//   interior: a = skip index (first node after the subtree), b = 0
+//   leaf:     a = first leaf-ordered primitive,            b = primitive count
+struct alignas(16) DKdNode {
+    float bmin[3];
+    uint32_t a;
+    float bmax[3];
+    uint32_t b;
+};
+static_assert(sizeof(DKdNode) == 32, "DKdNode must be 32 B");
+
+// Per-mesh header.
+struct alignas(16) DMesh {
+    uint32_t kd_base;    // first DKdNode of this mesh
+    uint32_t kd_count;   // number of DKdNodes
+    uint32_t leaf_base;  // first leaf-ordered hit record / prim id
+    uint32_t shade_base; // first shading record (original triangle order)
+};
+
+// Hit-test record, 64 B, stored once per (leaf, triangle) in leaf order so a
+// leaf's triangles stream contiguously (the reference keeps by-value copies in
+// every leaf too, scene.cpp:222-223):
+//   q0 = v0.xyz, N.x   q1 = N.yz, e0.xy   q2 = e0.z, e1.xyz   q3 = d00 d01 d11 inv_den
+// (triangle::update, scene.cpp:91-107).
+// Shading record, 64 B, original triangle order, fetched for the winning hit only:
+//   s0 = n0.xyz, n1.x  s1 = n1.yz, n2.xy  s2 = n2.z, uv0.xy, uv1.x  s3 = uv1.y, uv2.xy, 0
+
+struct DSampler {
+    uint32_t kind;
+    float r, g, b;
+    uint32_t texture, mode, pad0, pad1;
+};
+
+struct DTexture {
+    const float* rgb;
+    uint32_t w, h;
+};
+
+struct DScene {
+    const DNode* nodes;
+    const DMesh* meshes;
+    const DKdNode* kd;
+    const float4* tri_hit;     // 4 float4 per leaf-ordered primitive
+    const uint32_t* leaf_prim; // original triangle index per leaf-ordered primitive
+    const float4* tri_shade;   // 4 float4 per original triangle
+    const DSampler* samplers;
+    const DTexture* textures;
+    uint32_t num_nodes;
+    uint32_t bg_kind;
+    float bg_r, bg_g, bg_b;
+    uint32_t bg_texture, bg_mode;
+    float cam_x, cam_y, cam_z;
+};
+
+// abstract_pathtracer.cpp:20-25
+struct DView {
+    float fx, fy, fz; // forward
+    float rx, ry, rz; // right
+    float ux, uy, uz; // up
+    float h2, w2;
+    uint32_t width, height;
+};
+
+// ---------------------------------------------------------------- vec helpers
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{ x, y, z }; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 mulv(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+    return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+__device__ __forceinline__ V3 mix(V3 x, V3 y, float a) { return x * (1.0f - a) + y * a; }
+
+// glm mat4 * vec4(p, w) -> xyz; column-major m[c*4+r].
+__device__ __forceinline__ V3 mat_point(const float* __restrict__ m, V3 p, float w)
+{
+    V3 r;
+    r.x = (m[0] * p.x + m[4] * p.y) + (m[8] * p.z + m[12] * w);
+    r.y = (m[1] * p.x + m[5] * p.y) + (m[9] * p.z + m[13] * w);
+    r.z = (m[2] * p.x + m[6] * p.y) + (m[10] * p.z + m[14] * w);
+    return r;
+}
+
+// ---------------------------------------------------------------- intersectors
+
+// scene.cpp:58-75  bounding_box::intersect (quirks kept: six divides, NaN-ignoring
+// fmin/fmax, and the `t9 != -1` test that rejects an entry distance of exactly -1).
+__device__ __forceinline__ bool box_intersect(float minx, float miny, float minz, float maxx, float maxy,
+                                              float maxz, V3 o, V3 d)
+{
+    const float t1 = (minx - o.x) / d.x;
+    const float t2 = (maxx - o.x) / d.x;
+    const float t3 = (miny - o.y) / d.y;
+    const float t4 = (maxy - o.y) / d.y;
+    const float t5 = (minz - o.z) / d.z;
+    const float t6 = (maxz - o.z) / d.z;
+    const float t7 = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    const float t8 = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    const float t9 = (t8 < 0 || t7 > t8) ? -1.0f : t7;
+    return t9 != -1.0f;
+}
+
+// Closest-hit record carried through the node loop.  For a triangle a* holds the
+// barycentrics (u,v,w of scene.cpp:78-89); for a sphere it holds the local hit
+// position, from which normal and uv are rebuilt for the winner only.
+struct Hit {
+    float d0;   // length2(pos_world - origin), scene.cpp:383
+    int node;   // index in scene.nodes, -1 = miss
+    int prim;   // leaf-ordered primitive slot (mesh) or -1 (sphere)
+    float a0, a1, a2;
+    V3 pw;      // world position, scene.cpp:375
+};
+
+// scene.cpp:142-186 mesh::intersect_triangle up to the hit decision, plus the
+// distance bookkeeping of intersect_internal (scene.cpp:196-202).  Returns true
+// and updates (best_d, bar, p) when this triangle is hit and strictly closer.
+__device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o,
+                                         V3 d, float& best_d, V3& bar_out, V3& p_out)
+{
+    const V3 v0 = mk(q0.x, q0.y, q0.z);
+    const V3 N = mk(q0.w, q1.x, q1.y);
+    const V3 l = o - v0;
+    const float distance = dot(l, N);
+    if (distance < 0) return false;
+    const float cosine = dot(d, N);
+    if (cosine >= 0) return false;
+    const V3 projection = o + d * (distance / -cosine);
+    // triangle::baricentric, scene.cpp:78-89
+    const V3 e0 = mk(q1.z, q1.w, q2.x);
+    const V3 e1 = mk(q2.y, q2.z, q2.w);
+    const V3 v2 = projection - v0;
+    const float d20 = dot(v2, e0);
+    const float d21 = dot(v2, e1);
+    const float v = (q3.z * d20 - q3.y * d21) * q3.w;
+    const float w = (q3.x * d21 - q3.y * d20) * q3.w;
+    const float u = 1.0f - v - w;
+    if (u >= 0 && v >= 0 && w >= 0) {
+        const V3 dv = o - projection;
+        const float dd = dot(dv, dv);
+        if (dd < best_d) {
+            best_d = dd;
+            bar_out = mk(u, v, w);
+            p_out = projection;
+            return true;
+        }
+    }
+    return false;
+}
+
+// mesh::intersect + intersect_internal, scene.cpp:115-121,188-212, on the
+// flattened preorder tree.  The reference's recursion "box hit -> own triangles,
+// then left subtree, then right subtree" is the loop "box hit or leaf -> i+1,
+// interior box miss -> skip"; visiting order and the strict `<` are unchanged, so
+// exact ties resolve to the same primitive.  No stack is needed because the
+// reference never orders or prunes children.
+__device__ __forceinline__ bool mesh_intersect(const DScene& S, const DMesh mesh, V3 o, V3 d, bool lane_on,
+                                               int& prim_out, V3& bar_out, V3& p_out)
+{
+    float best_d = 3.402823466e+38f;
+    bool found = false;
+    if (mesh.kd_count == 1u) {
+        // Single-leaf mesh (plane.obj, cube.obj: the 1.5x rule keeps them whole).
+        // Every lane walks the same triangles, so the records come in through
+        // wave-uniform (scalar) loads and only the box test is per lane.
+        const DKdNode kn = S.kd[mesh.kd_base];
+        const bool inside = lane_on && box_intersect(kn.bmin[0], kn.bmin[1], kn.bmin[2], kn.bmax[0], kn.bmax[1],
+                                                     kn.bmax[2], o, d);
+        if (__builtin_amdgcn_ballot_w64(inside) != 0ull) {
+            const uint32_t first = mesh.leaf_base + kn.a;
+            for (uint32_t k = 0; k < kn.b; ++k) {
+                const float4* t = S.tri_hit + (size_t)(first + k) * 4;
+                const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
+                if (inside && tri_test(q0, q1, q2, q3, o, d, best_d, bar_out, p_out)) {
+                    prim_out = (int)(first + k);
+                    found = true;
+                }
+            }
+        }
+        return found;
+    }
+    const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
+    uint32_t i = lane_on ? 0u : mesh.kd_count;
+    while (i < mesh.kd_count) {
+        const float4 n0 = reinterpret_cast<const float4*>(kd + i)[0];
+        const float4 n1 = reinterpret_cast<const float4*>(kd + i)[1];
+        const uint32_t a = __float_as_uint(n0.w);
+        const uint32_t b = __float_as_uint(n1.w);
+        const bool hit = box_intersect(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, o, d);
+        if (hit && b != 0u) {
+            const uint32_t first = mesh.leaf_base + a;
+            for (uint32_t k = 0; k < b; ++k) {
+                const float4* t = S.tri_hit + (size_t)(first + k) * 4;
+                const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
+                if (tri_test(q0, q1, q2, q3, o, d, best_d, bar_out, p_out)) {
+                    prim_out = (int)(first + k);
+                    found = true;
+                }
+            }
+        }
+        i = (hit || b != 0u) ? i + 1u : a;
+    }
+    return found;
+}
+
+// sphere::intersect up to the hit position, scene.cpp:401-432.
+__device__ __forceinline__ bool sphere_intersect(V3 o, V3 d, V3& p_out)
+{
+    const float projection = dot(mk(0.0f, 0.0f, 0.0f) - o, d);
+    const float sq_distance = dot(o, o) - projection * projection;
+    if (sq_distance > 1.0f) return false;
+    const float offset = sqrtf(1.0f - sq_distance);
+    const float t1 = projection - offset;
+    const float t2 = projection + offset;
+    if (t1 < 0 && t2 < 0) return false;
+    p_out = o + d * (t1 >= 0.0f ? t1 : t2);
+    return true;
+}
+
+// scene::cast_ray, scene.cpp:355-399.  All lanes of a wave walk the node table
+// together (there is no top-level structure in the reference: every ray tests
+// every node), so the node record and the sphere/mesh branch are wave-uniform.
+__device__ __forceinline__ void intersect_scene(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
+{
+    best.d0 = 3.402823466e+38f;
+    best.node = -1;
+    best.prim = -1;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    best.pw = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t n = 0; n < S.num_nodes; ++n) {
+        const DNode* __restrict__ nd = S.nodes + n;
+        // operator*(mat4, ray), scene.cpp:18-23
+        const V3 lo = mat_point(nd->inv, o, 1.0f);
+        const V3 ld = normalize(mat_point(nd->inv, d, 0.0f));
+        bool hit;
+        int prim = -1;
+        V3 p = mk(0.0f, 0.0f, 0.0f), a = mk(0.0f, 0.0f, 0.0f);
+        if (nd->kind == PTK_SHAPE_SPHERE) {
+            hit = lane_on && sphere_intersect(lo, ld, p);
+            a = p;
+        } else {
+            hit = mesh_intersect(S, S.meshes[nd->mesh], lo, ld, lane_on, prim, a, p);
+        }
+        if (hit) {
+            const V3 pw = mat_point(nd->xf, p, 1.0f); // scene.cpp:375
+            const V3 dv = pw - o;
+            const float d0 = dot(dv, dv);             // scene.cpp:383
+            if (d0 < best.d0) {                       // scene.cpp:386
+                best.d0 = d0;
+                best.node = (int)n;
+                best.prim = prim;
+                best.a0 = a.x;
+                best.a1 = a.y;
+                best.a2 = a.z;
+                best.pw = pw;
+            }
+        }
+    }
+}
+
+// Rebuilds raycast_result::normal / uv for the winning hit only (the reference
+// computes them for every candidate, scene.cpp:173-182,433-437; the values for
+// the winner are identical).  n_world: scene.cpp:378.
+__device__ __forceinline__ void hit_attributes(const DScene& S, const Hit& h, V3& n_world, float& uvx, float& uvy,
+                                               int& prim_id, float& u_out, float& v_out)
+{
+    const DNode* __restrict__ nd = S.nodes + h.node;
+    V3 nl;
+    if (h.prim < 0) {
+        // sphere: scene.cpp:433-437
+        nl = normalize(mk(h.a0, h.a1, h.a2));
+        uvx = atan2f(nl.x, nl.z) / 3.14159265358979323846f + 0.5f;
+        uvy = nl.y * 0.5f + 0.5f;
+        prim_id = -1;
+        u_out = uvx;
+        v_out = uvy;
+    } else {
+        const DMesh mesh = S.meshes[nd->mesh];
+        const uint32_t tri = S.leaf_prim[h.prim];
+        const float4* s = S.tri_shade + (size_t)(mesh.shade_base + tri) * 4;
+        const float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+        const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
+        nl = normalize(n0 * h.a0 + n1 * h.a1 + n2 * h.a2);                // scene.cpp:175-178
+        uvx = h.a0 * s2.y + h.a1 * s2.w + h.a2 * s3.y;                    // scene.cpp:179-182
+        uvy = h.a0 * s2.z + h.a1 * s3.x + h.a2 * s3.z;
+        prim_id = (int)tri;
+        u_out = h.a1;
+        v_out = h.a2;
+    }
+    n_world = normalize(mat_point(nd->nrm, nl, 0.0f));
+}
+
+// ---------------------------------------------------------------- samplers
+
+__device__ __forceinline__ V3 tex_pixel(const DTexture t, uint32_t x, uint32_t y)
+{
+    const float* p = t.rgb + ((size_t)y * t.w + x) * 3; // sampler.cpp:67-70
+    return mk(p[0], p[1], p[2]);
+}
+
+// image::sample, sampler.cpp:36-61
+__device__ __forceinline__ V3 image_sample(const DTexture t, uint32_t mode, float u, float v)
+{
+    const float u0 = u - floorf(u);
+    const float v0 = v - floorf(v);
+    const float x = u0 * (float)t.w;
+    const float y = v0 * (float)t.h;
+    if (mode == PTK_MODE_LINEAR) {
+        const uint32_t x0 = (uint32_t)floorf(x) % t.w;
+        const uint32_t x1 = (uint32_t)ceilf(x) % t.w;
+        const uint32_t y0 = (uint32_t)floorf(y) % t.h;
+        const uint32_t y1 = (uint32_t)ceilf(y) % t.h;
+        const V3 a = mix(tex_pixel(t, x0, y0), tex_pixel(t, x1, y0), x - (float)x0);
+        const V3 b = mix(tex_pixel(t, x0, y1), tex_pixel(t, x1, y1), x - (float)x0);
+        return mix(a, b, y - (float)y0);
+    }
+    const uint32_t ix = (uint32_t)roundf(x) % t.w;
+    const uint32_t iy = (uint32_t)roundf(y) % t.h;
+    return tex_pixel(t, ix, iy);
+}
+
+// sampler_2d::sample: color_sampler (sampler.h:58) or image
+__device__ __forceinline__ V3 sampler_sample(const DScene& S, uint32_t idx, float u, float v)
+{
+    const DSampler sd = S.samplers[idx];
+    if (sd.kind == PTK_SAMPLER_COLOR) return mk(sd.r, sd.g, sd.b);
+    return image_sample(S.textures[sd.texture], sd.mode, u, v);
+}
+
+// scene.background->sample(dir): color_sampler or equirectangular_map (sampler.cpp:116-124)
+__device__ __forceinline__ V3 background_sample(const DScene& S, V3 dir)
+{
+    if (S.bg_kind == PTK_BACKGROUND_COLOR) return mk(S.bg_r, S.bg_g, S.bg_b);
+    const V3 n = normalize(dir);
+    const float u = atan2f(n.x, n.z) / (2.0f * 3.14159265358979323846f) + 0.5f;
+    const float v = asinf(n.y) / 3.14159265358979323846f - 0.5f;
+    return image_sample(S.textures[S.bg_texture], S.bg_mode, u, v);
+}
+
+// ---------------------------------------------------------------- random numbers
+// Counter-based Philox4x32-10: counter = (pixel, sample_lo, sample_hi, block),
+// key = seed.  One block yields four of the path's 12 dimensions in the
+// reference's draw order (fx, fy, then z, phi per bounce: abstract_pathtracer.cpp:76-77,
+// rng.cpp:27-29).  Replaces the thread_local mt19937 of rng.h:15.
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1)
+{
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
+
+// Dimension pair (2*j, 2*j+1) of path (pixel, sample): j = 0 primary jitter,
+// j = 1 + bounce for the hemisphere draw of that bounce.
+__device__ __forceinline__ void rng_pair(uint64_t seed, uint32_t pixel, uint64_t sample, uint32_t j, float& u1,
+                                         float& u2)
+{
+    const uint4 r = philox4x32_10(pixel, (uint32_t)sample, (uint32_t)(sample >> 32), j >> 1, (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+    u1 = u01((j & 1u) ? r.z : r.x);
+    u2 = u01((j & 1u) ? r.w : r.y);
+}
+
+// rng::hemisphere, rng.cpp:12-36
+__device__ __forceinline__ V3 hemisphere_dir(V3 n, float u1, float u2)
+{
+    V3 t;
+    if (fabsf(n.x) > fabsf(n.y)) t = normalize(mk(n.z, 0.0f, -n.x));
+    else t = normalize(mk(0.0f, -n.z, n.y));
+    const V3 b = cross(n, t);
+    const float z = u1;
+    const float r = sqrtf(1.0f - z * z);
+    const float phi = 3.14159265358979323846f * 2.0f * u2;
+    const float tx = r * cosf(phi), ty = r * sinf(phi);
+    return t * tx + b * ty + n * z;
+}
+
+// abstract_pathtracer.cpp:74-83
+__device__ __forceinline__ V3 primary_dir(const DView& V, uint32_t x, uint32_t y, float u1, float u2)
+{
+    const float fx = u1 - 0.5f + (float)x;
+    const float fy = u2 - 0.5f + (float)y;
+    const float x_factor = fx / (float)V.width * 2.0f - 1.0f;
+    const float y_factor = 1.0f - fy / (float)V.height * 2.0f;
+    const V3 fwd = mk(V.fx, V.fy, V.fz), right = mk(V.rx, V.ry, V.rz), up = mk(V.ux, V.uy, V.uz);
+    return normalize(fwd + right * x_factor * V.w2 + up * y_factor * V.h2);
+}
+
+} // namespace ptk

@@ -1,0 +1,409 @@
+"""Host-side scene graph for the Python harness (tests, bench.py, smoke): the same
+objects the reference's callers build — rt::scene / scene_node / mesh / material /
+samplers (reference src/Pathtracing/scene.h:27-37,133-140,244-394, sampler.h:48-156)
+— plus the JSON / OBJ / image ingest of src/PathtracingUtility/scene_loader.cpp and
+mesh_loader.cpp, and the flattening to include/ptk.h's ptk_scene_desc.
+
+The C++ drop-in (pathtracing_amd/host) is the product's host API; this module exists
+so Python tests and bench.py can drive the C ABI with the same scenes.
+"""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+
+from . import _abi, glmath
+
+
+class ColorSampler:
+    """rt::color_sampler, sampler.h:48-63."""
+
+    def __init__(self, color):
+        self.color = np.asarray(color, dtype=np.float32)
+
+
+class Image:
+    """rt::image, sampler.h:73-140: float RGB, row-major, row 0 = first stored row."""
+
+    def __init__(self, pixels, mode="linear"):
+        pixels = np.ascontiguousarray(pixels, dtype=np.float32)
+        assert pixels.ndim == 3 and pixels.shape[2] == 3
+        self.pixels = pixels
+        self.mode = mode
+
+    @property
+    def width(self):
+        return self.pixels.shape[1]
+
+    @property
+    def height(self):
+        return self.pixels.shape[0]
+
+    def to_ldr(self):
+        """image::to_ldr, sampler.cpp:98-113."""
+        if float(self.pixels.max(initial=0.0)) > 1.0:
+            self.pixels = (np.float32(1.0) - np.exp(-self.pixels)).astype(np.float32)
+
+
+class EquirectangularMap:
+    """rt::equirectangular_map, sampler.h:145-156."""
+
+    def __init__(self, image):
+        self.image = image
+
+
+def _decode_rgbe(path):
+    """Radiance .hdr -> float RGB (stb_image.h stbi__hdr_load / stbi__hdr_convert semantics)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    header_done = False
+    while not header_done:
+        end = data.index(b"\n", pos)
+        line = data[pos:end]
+        pos = end + 1
+        if line == b"":
+            header_done = True
+    end = data.index(b"\n", pos)
+    dims = data[pos:end].split()
+    pos = end + 1
+    assert dims[0] == b"-Y" and dims[2] == b"+X", "unsupported .hdr orientation"
+    h, w = int(dims[1]), int(dims[3])
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    for y in range(h):
+        if w < 8 or w >= 32768 or buf[pos] != 2 or buf[pos + 1] != 2 or (buf[pos + 2] & 0x80):
+            raise ValueError("flat (non-RLE) .hdr scanlines are not supported by this loader")
+        assert (int(buf[pos + 2]) << 8 | int(buf[pos + 3])) == w
+        pos += 4
+        for ch in range(4):
+            x = 0
+            while x < w:
+                count = int(buf[pos])
+                pos += 1
+                if count > 128:
+                    count -= 128
+                    out[y, x : x + count, ch] = buf[pos]
+                    pos += 1
+                else:
+                    out[y, x : x + count, ch] = buf[pos : pos + count]
+                    pos += count
+                x += count
+    e = out[..., 3].astype(np.int32)
+    scale = np.ldexp(np.float32(1.0), e - (128 + 8)).astype(np.float32)
+    rgb = out[..., :3].astype(np.float32) * scale[..., None]
+    rgb[e == 0] = 0.0
+    return rgb.astype(np.float32)
+
+
+def load_image(path):
+    """image::load, sampler.cpp:78-96: stbi_loadf(..., 3) with vertical flip.  8-bit
+    sources are linearised like stb (pow(v/255, 2.2), stb_image.h:1799-1811); .hdr is
+    RGBE float.  JPEG decoding uses PIL (the reference uses stb's decoder; texel values
+    may differ by a level or two — they are inputs of the hot path, not part of it)."""
+    if path.lower().endswith(".hdr"):
+        px = _decode_rgbe(path)
+    else:
+        from PIL import Image as PILImage
+
+        u8 = np.asarray(PILImage.open(path).convert("RGB"), dtype=np.uint8)
+        lin = np.power((u8.astype(np.float32) / np.float32(255.0)).astype(np.float64), float(np.float32(2.2)))
+        px = lin.astype(np.float32)
+    return Image(px[::-1].copy())
+
+
+def load_meshes_from_wavefront(path):
+    """load_meshes_from_wavefront, mesh_loader.cpp:12-158 (same grammar: v / vn / vt /
+    f in four index styles / o|g starts a mesh; only the first three corners of a face).
+    Returns {name: (T,3,8) float32 array of (position, normal, uv)}."""
+    num = r"(-?[\d.]+)"
+    r_vertex = re.compile(r"v\s+" + num + r"\s+" + num + r"\s+" + num)
+    r_normal = re.compile(r"vn\s+" + num + r"\s+" + num + r"\s+" + num)
+    r_uv = re.compile(r"vt\s+" + num + r"\s+" + num)
+    r_object = re.compile(r"[og]\s+(.+)")
+    r_face0 = re.compile(r"f\s+([0-9]+)\s+([0-9]+)\s+([0-9]+)")
+    r_face1 = re.compile(r"f\s+([0-9]+)//([0-9]+)\s+([0-9]+)//([0-9]+)\s+([0-9]+)//([0-9]+)")
+    r_face2 = re.compile(r"f\s+([0-9]+)/([0-9]+)\s+([0-9]+)/([0-9]+)\s+([0-9]+)/([0-9]+)")
+    r_face3 = re.compile(r"f\s+([0-9]+)/([0-9]+)/([0-9]+)\s+([0-9]+)/([0-9]+)/([0-9]+)\s+([0-9]+)/([0-9]+)/([0-9]+)")
+    result = {}
+    name = "default"
+    tris = []
+    vs, ns, ts = [], [], []
+
+    def flush():
+        nonlocal tris
+        if tris:
+            result[name] = np.asarray(tris, dtype=np.float32).reshape(-1, 3, 8)
+            tris = []
+
+    with open(path, "r") as f:
+        for line in f.read().split("\n"):
+            m = r_vertex.search(line)
+            if m:
+                vs.append([float(m.group(i)) for i in (1, 2, 3)])
+                continue
+            m = r_normal.search(line)
+            if m:
+                ns.append([float(m.group(i)) for i in (1, 2, 3)])
+                continue
+            m = r_uv.search(line)
+            if m:
+                ts.append([float(m.group(i)) for i in (1, 2)])
+                continue
+            m = r_face0.search(line)
+            if m:
+                tris.append([vs[int(m.group(1 + i)) - 1] + [0, 0, 0] + [0, 0] for i in range(3)])
+                continue
+            m = r_face1.search(line)
+            if m:
+                tris.append([vs[int(m.group(1 + 2 * i)) - 1] + ns[int(m.group(2 + 2 * i)) - 1] + [0, 0] for i in range(3)])
+                continue
+            m = r_face2.search(line)
+            if m:
+                tris.append([vs[int(m.group(1 + 2 * i)) - 1] + [0, 0, 0] + ts[int(m.group(2 + 2 * i)) - 1] for i in range(3)])
+                continue
+            m = r_face3.search(line)
+            if m:
+                tris.append(
+                    [vs[int(m.group(1 + 3 * i)) - 1] + ns[int(m.group(3 + 3 * i)) - 1] + ts[int(m.group(2 + 3 * i)) - 1] for i in range(3)]
+                )
+                continue
+            m = r_object.search(line)
+            if m:
+                flush()
+                name = m.group(1)
+    flush()
+    return result
+
+
+class Material:
+    """rt::material, scene.h:133-140 with the defaults of scene.cpp:443-449."""
+
+    def __init__(self):
+        self.albedo = ColorSampler([1.0, 1.0, 1.0])
+        self.emission = ColorSampler([0.0, 0.0, 0.0])
+        self.roughness = ColorSampler([1.0, 1.0, 1.0])
+        self.metallic = ColorSampler([0.0, 0.0, 0.0])
+
+
+class Mesh:
+    """rt::mesh: triangles as a (T,3,8) float32 array (position3, normal3, uv2)."""
+
+    def __init__(self, triangles):
+        self.triangles = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 8)
+
+
+class Sphere:
+    """rt::sphere, scene.h:231-239 (unit sphere at the node's origin)."""
+
+
+class SceneNode:
+    """rt::scene_node, scene.h:284-350; transform ops post-multiply (scene.cpp:301-329)."""
+
+    def __init__(self):
+        self.transform = glmath.identity()
+        self.material = Material()
+        self.shape = None
+
+    def load_identity(self):
+        self.transform = glmath.identity()
+
+    def translate(self, t):
+        self.transform = glmath.mat_mul(self.transform, glmath.translate(t))
+
+    def rotate(self, axis, angle):
+        self.transform = glmath.mat_mul(self.transform, glmath.rotate(angle, axis))
+
+    def scale(self, s):
+        self.transform = glmath.mat_mul(self.transform, glmath.scale(s))
+
+    def multiply(self, m):
+        self.transform = glmath.mat_mul(self.transform, m)
+
+    @property
+    def inverse_transform(self):
+        return glmath.inverse(self.transform)  # scene.cpp:297
+
+    @property
+    def normal_transform(self):
+        return glmath.transpose(self.inverse_transform)  # scene.cpp:298
+
+
+class Camera:
+    def __init__(self):
+        self.position = np.zeros(3, dtype=np.float32)
+        self.direction = np.array([0.0, 0.0, -1.0], dtype=np.float32)
+
+    def set_direction(self, d):
+        self.direction = glmath.normalize(d)  # scene.h:33
+
+
+class Scene:
+    """rt::scene, scene.h:355-394."""
+
+    def __init__(self):
+        self.camera = Camera()
+        self.background = ColorSampler([0.0, 0.0, 0.0])  # scene.cpp:350-353
+        self.nodes = []
+
+    # ---- flattening to ptk_scene_desc -------------------------------------
+    def to_desc(self):
+        """Returns (SceneDesc, keepalive) — keepalive owns every array the desc points to."""
+        keep = []
+        meshes, mesh_index = [], {}
+        samplers, sampler_index = [], {}
+        textures, texture_index = [], {}
+
+        def tex_id(img):
+            if id(img) not in texture_index:
+                texture_index[id(img)] = len(textures)
+                textures.append(img)
+            return texture_index[id(img)]
+
+        def sampler_id(s):
+            if id(s) not in sampler_index:
+                sampler_index[id(s)] = len(samplers)
+                samplers.append(s)
+            return sampler_index[id(s)]
+
+        node_arr = (_abi.NodeDesc * max(1, len(self.nodes)))()
+        for i, n in enumerate(self.nodes):
+            nd = node_arr[i]
+            nd.transform[:] = n.transform.reshape(-1).tolist()
+            nd.inv_transform[:] = n.inverse_transform.reshape(-1).tolist()
+            nd.normal_transform[:] = n.normal_transform.reshape(-1).tolist()
+            if isinstance(n.shape, Sphere):
+                nd.shape_kind = _abi.PTK_SHAPE_SPHERE
+            elif isinstance(n.shape, Mesh):
+                nd.shape_kind = _abi.PTK_SHAPE_MESH
+                if id(n.shape) not in mesh_index:
+                    mesh_index[id(n.shape)] = len(meshes)
+                    meshes.append(n.shape)
+                nd.mesh = mesh_index[id(n.shape)]
+            else:
+                nd.shape_kind = 0xFFFFFFFF  # no shape: rejected by ptk_scene_upload
+            nd.albedo = sampler_id(n.material.albedo)
+            nd.emission = sampler_id(n.material.emission)
+            nd.roughness = sampler_id(n.material.roughness)
+            nd.metallic = sampler_id(n.material.metallic)
+
+        samp_arr = (_abi.SamplerDesc * max(1, len(samplers)))()
+        for i, s in enumerate(samplers):
+            if isinstance(s, ColorSampler):
+                samp_arr[i].kind = _abi.PTK_SAMPLER_COLOR
+                samp_arr[i].color[:] = s.color.tolist()
+            else:
+                samp_arr[i].kind = _abi.PTK_SAMPLER_IMAGE
+                samp_arr[i].texture = tex_id(s)
+                samp_arr[i].mode = _abi.PTK_MODE_NEAREST if s.mode == "nearest" else _abi.PTK_MODE_LINEAR
+
+        desc = _abi.SceneDesc()
+        bg = self.background
+        if isinstance(bg, EquirectangularMap):
+            desc.background.kind = _abi.PTK_BACKGROUND_EQUIRECT
+            desc.background.texture = tex_id(bg.image)
+            desc.background.mode = _abi.PTK_MODE_NEAREST if bg.image.mode == "nearest" else _abi.PTK_MODE_LINEAR
+        else:
+            desc.background.kind = _abi.PTK_BACKGROUND_COLOR
+            desc.background.color[:] = bg.color.tolist()
+
+        tex_arr = (_abi.TextureDesc * max(1, len(textures)))()
+        for i, t in enumerate(textures):
+            tex_arr[i].width = t.width
+            tex_arr[i].height = t.height
+            tex_arr[i].rgb = t.pixels.ctypes.data
+            keep.append(t.pixels)
+
+        mesh_arr = (_abi.MeshDesc * max(1, len(meshes)))()
+        for i, m in enumerate(meshes):
+            mesh_arr[i].triangles = m.triangles.ctypes.data
+            mesh_arr[i].num_triangles = m.triangles.shape[0]
+            keep.append(m.triangles)
+
+        desc.nodes = C.cast(node_arr, C.c_void_p)
+        desc.num_nodes = len(self.nodes)
+        desc.meshes = C.cast(mesh_arr, C.c_void_p)
+        desc.num_meshes = len(meshes)
+        desc.samplers = C.cast(samp_arr, C.c_void_p)
+        desc.num_samplers = len(samplers)
+        desc.textures = C.cast(tex_arr, C.c_void_p)
+        desc.num_textures = len(textures)
+        desc.camera.position[:] = self.camera.position.tolist()
+        desc.camera.direction[:] = self.camera.direction.tolist()
+        keep += [node_arr, samp_arr, tex_arr, mesh_arr, meshes, samplers, textures]
+        return desc, keep
+
+
+def load_scene(file_name, asset_root=None):
+    """rt::utility::load_scene, scene_loader.cpp:39-195.  Asset paths in the JSON are
+    relative to the working directory in the reference (premake5.lua:170-172); here
+    they are resolved against `asset_root` (default: two levels above the scene file,
+    i.e. the directory that contains res/)."""
+    if asset_root is None:
+        asset_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(file_name))))
+    with open(file_name, "r") as f:
+        scene_def = json.load(f)
+    result = Scene()
+    meshes, samplers_2d, samplers_3d = {}, {}, {}
+
+    for mesh_def in scene_def.get("meshes", []):
+        ids = mesh_def["ids"]
+        for name, tris in load_meshes_from_wavefront(os.path.join(asset_root, mesh_def["file"])).items():
+            if name in ids:
+                meshes[name] = Mesh(tris)
+
+    cam = scene_def.get("camera")
+    if cam:
+        if "position" in cam:
+            result.camera.position = np.asarray(cam["position"], dtype=np.float32)
+        if "direction" in cam:
+            result.camera.set_direction(cam["direction"])
+
+    for sd in scene_def.get("samplers", []):
+        if "file" in sd:
+            image = load_image(os.path.join(asset_root, sd["file"]))
+            if sd.get("ldr"):
+                image.to_ldr()
+            if "mode" in sd:
+                image.mode = sd["mode"]
+            kind = sd.get("type", "image")
+            if kind == "image":
+                samplers_2d[sd["id"]] = image
+            elif kind == "equirectangular":
+                samplers_3d[sd["id"]] = EquirectangularMap(image)
+        elif "color" in sd:
+            s = ColorSampler(sd["color"])
+            samplers_2d[sd["id"]] = s
+            samplers_3d[sd["id"]] = s
+
+    bg = scene_def.get("background")
+    if bg and "color" in bg:
+        result.background = samplers_3d[bg["color"]]  # KeyError like .at() (scene_loader.cpp:139)
+
+    for nd in scene_def.get("nodes", []):
+        node = SceneNode()
+        if "translate" in nd:
+            node.translate(nd["translate"])
+        if "rotate" in nd:
+            ax, ay, az = nd["rotate"]
+            node.multiply(
+                glmath.mat_mul(
+                    glmath.mat_mul(glmath.rotate(glmath.radians(az), [0.0, 0.0, 1.0]), glmath.rotate(glmath.radians(ay), [0.0, 1.0, 0.0])),
+                    glmath.rotate(glmath.radians(ax), [1.0, 0.0, 0.0]),
+                )
+            )
+        if "scale" in nd:
+            node.scale(nd["scale"])
+        if "mesh" in nd:
+            node.shape = meshes[nd["mesh"]]
+        elif nd.get("shape") == "sphere":
+            node.shape = Sphere()
+        mat = nd.get("material")
+        if mat:
+            for key in ("albedo", "emission", "roughness", "metallic"):
+                if key in mat:
+                    setattr(node.material, key, samplers_2d[mat[key]])
+        result.nodes.append(node)
+    return result

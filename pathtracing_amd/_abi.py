@@ -137,6 +137,13 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
         )
+    # torch (used by the harness for device buffers, streams and torch.distributed) ships
+    # its own libamdhip64.so.7; load it first so libptk.so binds to that same HIP runtime
+    # instead of bringing a second one into the process (two runtimes cannot share a GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -1,0 +1,69 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ASSETS = os.path.join(ROOT, "tests", "golden", "assets")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def scene_path(name):
+    return os.path.join(ASSETS, "res", "scenes", name + ".json")
+
+
+_scene_cache = {}
+
+
+def get_scene(name):
+    from pathtracing_amd import load_scene
+    if name not in _scene_cache:
+        _scene_cache[name] = load_scene(scene_path(name))
+    return _scene_cache[name]
+
+
+_oracle_cache = {}
+
+
+def get_oracle(name):
+    from oracle import oracle
+    if name not in _oracle_cache:
+        _oracle_cache[name] = oracle.OracleScene(get_scene(name))
+    return _oracle_cache[name]
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One ptk context on cuda:0 for the whole GPU session (the HIP library must load: no fallback)."""
+    from pathtracing_amd import Context
+    ctx = Context(0)
+    yield ctx
+    ctx.close()
+
+
+def random_soup(n_tris, seed, extent=1.0, size=0.08):
+    """Random small triangles with normals and uvs: a KD-tree with real depth."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-extent, extent, (n_tris, 1, 3)).astype(np.float32)
+    p = c + rng.normal(0, size, (n_tris, 3, 3)).astype(np.float32)
+    nrm = rng.normal(0, 1, (n_tris, 3, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+    uv = rng.uniform(0, 1, (n_tris, 3, 2)).astype(np.float32)
+    return np.concatenate([p, nrm, uv], axis=2).astype(np.float32)
+
+
+def random_rays(n, seed, lo, hi):
+    """SURVEY §8d batch (iii): origins uniform in a box, directions uniform on the sphere."""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d

@@ -1,0 +1,125 @@
+"""GPU parity, closest hit: ptk_intersect_batch (HIP) vs the CPU oracle on the same rays.
+
+Bar (BASELINE.json north_star): node and primitive ids bit-exact; t, u, v within 1e-5
+relative.  Batches follow SURVEY §8d: (i) primary rays through pixel centres, (ii) first-
+bounce secondary rays of the Philox render, (iii) random rays in the scene box.
+"""
+import numpy as np
+import pytest
+
+from conftest import get_oracle, get_scene, random_rays, random_soup
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["room", "materials", "mario", "furnace"]
+REL = 1e-5
+
+
+def check_batch(gpu, ora, exact_attrs=False):
+    assert np.array_equal(gpu["node"], ora["node"]), f"{(gpu['node'] != ora['node']).sum()} node ids differ"
+    assert np.array_equal(gpu["prim"], ora["prim"]), f"{(gpu['prim'] != ora['prim']).sum()} primitive ids differ"
+    hit = ora["node"] >= 0
+    for k in ("t", "u", "v"):
+        a, b = gpu[k][hit], ora[k][hit]
+        err = np.abs(a - b) / np.maximum(np.abs(b), 1.0 if k != "t" else 1e-30)
+        assert err.max(initial=0.0) <= REL, (k, err.max())
+    np.testing.assert_allclose(gpu["position"][hit], ora["position"][hit], rtol=REL, atol=1e-5)
+    np.testing.assert_allclose(gpu["normal"][hit], ora["normal"][hit], rtol=0, atol=2e-5)
+    if exact_attrs:
+        assert np.array_equal(gpu["t"][hit], ora["t"][hit])
+        assert np.array_equal(gpu["position"][hit], ora["position"][hit])
+
+
+def centre_rays(ora, w, h):
+    ys, xs = np.mgrid[0:h, 0:w]
+    xy = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.uint32)
+    u12 = np.full((w * h, 2), 0.5, np.float32)
+    return ora.primary_rays(w, h, np.pi / 4, xy, u12)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_primary_centre_rays(gpu_ctx, name):
+    ora = get_oracle(name)
+    gpu_ctx.upload(get_scene(name))
+    o, d = centre_rays(ora, 256, 256)
+    check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d), exact_attrs=True)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_secondary_rays(gpu_ctx, name):
+    ora = get_oracle(name)
+    gpu_ctx.upload(get_scene(name))
+    n = 65536
+    pixel = np.arange(n, dtype=np.uint32) % (256 * 256)
+    sample = np.arange(n, dtype=np.uint64) // 7
+    o, d, valid = ora.secondary_rays(256, 256, np.pi / 4, 1234, pixel, sample)
+    o, d = o[valid], d[valid]
+    assert len(o) > 1000 or name == "furnace"
+    check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d))
+
+
+@pytest.mark.parametrize("name,lo,hi", [("room", -10, 10), ("materials", -8, 8), ("mario", -10, 10), ("furnace", -3, 3)])
+def test_random_rays(gpu_ctx, name, lo, hi):
+    ora = get_oracle(name)
+    gpu_ctx.upload(get_scene(name))
+    n = 1_000_000 if name != "mario" else 200_000
+    o, d = random_rays(n, 12345, lo, hi)
+    check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d))
+
+
+def test_deep_kd_soup(gpu_ctx):
+    """A 30k-triangle soup: deep KD-tree, duplicated leaf triangles, scaled + rotated node."""
+    from oracle import oracle
+    from pathtracing_amd import scene as S
+    sc = S.Scene()
+    node = S.SceneNode()
+    node.translate([0.3, -0.2, 0.1])
+    node.rotate([0.2, 1.0, 0.4], 0.7)
+    node.scale([1.5, 0.8, 1.2])
+    node.shape = S.Mesh(random_soup(30000, 7))
+    sc.nodes.append(node)
+    sph = S.SceneNode()
+    sph.translate([0.0, 0.0, -0.5])
+    sph.scale([0.4, 0.4, 0.4])
+    sph.shape = S.Sphere()
+    sc.nodes.append(sph)
+    ora = oracle.OracleScene(sc)
+    gpu_ctx.upload(sc)
+    info = gpu_ctx.kd_info(0)
+    assert info.max_depth >= 8 and info.num_leaf_prims > 30000
+    o, d = random_rays(200_000, 99, -2.5, 2.5)
+    g, r = gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d)
+    check_batch(g, r)
+    assert (r["prim"] >= 0).sum() > 20000
+
+
+def test_ragged_and_empty_batches(gpu_ctx):
+    ora = get_oracle("room")
+    gpu_ctx.upload(get_scene("room"))
+    for n in (1, 63, 64, 65, 255, 257, 1000):
+        o, d = random_rays(n, n, -10, 10)
+        check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d))
+    out = gpu_ctx.intersect_batch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert out["node"].shape == (0,)
+
+
+def test_axis_aligned_and_degenerate_rays(gpu_ctx):
+    """Zero direction components (inf/NaN slab terms, scene.cpp:60-67) and origins on box faces."""
+    ora = get_oracle("room")
+    gpu_ctx.upload(get_scene("room"))
+    dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1],
+                     [1, 1, 0], [0, 1, 1], [1, 0, -1]], np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    origins = np.array([[0, 0, 0], [0, 0, 29], [-6.5, -5, -6.5], [6, -6, -6], [0, -10, 0], [10, 0, 0],
+                        [0, -7, 0], [0, 10, 0], [-10, -10, -10]], np.float32)
+    o = np.repeat(origins, len(dirs), axis=0)
+    d = np.tile(dirs, (len(origins), 1))
+    check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d))
+
+
+def test_empty_scene_misses(gpu_ctx):
+    from pathtracing_amd import scene as S
+    gpu_ctx.upload(S.Scene())
+    o, d = random_rays(1000, 3, -1, 1)
+    out = gpu_ctx.intersect_batch(o, d)
+    assert (out["node"] == -1).all() and (out["prim"] == -1).all()

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the path-tracing hot path on MI355X.
+
+Metric (BASELINE.json): Mpaths/s (+ Mrays/s) on the Room scene at 256x256.
+A step = one CLI iteration per GPU: every rank traces 256 samples per pixel of
+room.json at 256x256 (reference src/CLI/main.cpp:64-70: fov pi/4, 256 samples per
+iteration; depth 5) = 16.8 M paths, 83.9 M rays per GPU per step.  With N ranks the
+ranks take disjoint sample ranges of one N*256-spp iteration (weak scaling), their
+per-GPU HDR sum buffers are combined with one RCCL reduce to rank 0, and rank 0
+applies the running mean (abstract_pathtracer.cpp:88-90).  Scene tables and ray
+queues are resident in HBM before the timed region; nothing crosses PCIe inside it.
+
+Prints ONE JSON line on rank 0 (see the round contract): value = whole-job Mpaths/s.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCENE = os.path.join(ROOT, "tests", "golden", "assets", "res", "scenes", "room.json")
+W = H = 256
+SPI = 256
+FOV = math.pi / 4.0
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop)
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
+
+
+def flops_from_stats(st, costs, equirect):
+    """Algorithmic flops of a run from the oracle's operation counts (DESIGN.md 'Flop model')."""
+    f = 0
+    for k in ("path", "node", "kd_box", "tri_a", "tri_b", "tri_full", "tri_hit", "sphere", "sphere_hit", "node_hit",
+              "shade", "mesh_win"):
+        f += st[k] * costs[k]
+    f += (st["shade"] - st["mesh_win"]) * costs["sphere_win"]
+    f += st["miss"] * (costs["miss_equirect"] if equirect else costs["miss_color"])
+    return f
+
+
+def cpu_baseline(scene, target_seconds=12.0):
+    """The CPU restatement of the reference ("port"), timed on this box's host cores on a
+    bounded sample of the same workload (Room 256x256, fewer samples per pixel)."""
+    import numpy as np
+    from oracle import oracle
+    ora = oracle.OracleScene(scene)
+    # the GPU box's CPU share is 16; os.cpu_count() shows the whole machine there
+    cores = min(16, os.cpu_count() or 1)
+    cores = int(os.environ.get("PTK_BENCH_CPU_THREADS", cores))
+    t0 = time.perf_counter()
+    ora.render_samples(W, H, FOV, 0, 0, 4, threads=cores)
+    probe = time.perf_counter() - t0
+    spp = int(max(4, min(4096, 4 * target_seconds / max(probe, 1e-3))))
+    t0 = time.perf_counter()
+    _, rays, st = ora.render_samples_stats(W, H, FOV, 0, 0, spp, threads=cores)
+    dt = time.perf_counter() - t0
+    with open(os.path.join(ROOT, "tests", "golden", "flop_costs.json")) as f:
+        costs = json.load(f)
+    flops = flops_from_stats(st, costs, equirect=False)
+    paths = W * H * spp
+    return {
+        "value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+        "sample": f"room.json {W}x{H}, {spp} spp ({paths} paths, {rays} rays) in {dt:.1f} s, oracle/pt_oracle.c, "
+                  f"{cores} pthreads; the reference itself is unbuildable here (glm/spdlog absent)",
+        "mrays_per_s": rays / dt / 1e6,
+    }, flops / rays, rays / paths
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pathtracing_amd import Context, load_scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene = load_scene(SCENE)
+    ctx = Context(local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.upload(scene)
+    ctx.render_begin(W, H, FOV)
+    total = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
+    image = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
+
+    def step(it):
+        # rank r traces global samples [(it*world + r)*SPI, +SPI) of every pixel
+        ctx.render_samples_dev(0, (it * world + rank) * SPI, SPI, total.data_ptr())
+        if distributed:
+            dist.reduce(total, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            ctx.resolve_iteration_dev(total.data_ptr(), image.data_ptr(), SPI * world, it)
+
+    for it in range(args.warmup):
+        step(it)
+    torch.cuda.synchronize(dev)
+    ctx.reset_counters()
+    ctx.enable_timing(True)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        step(args.warmup + it)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+
+    paths, rays = ctx.counters()
+    timing = ctx.timing()
+    ctx.enable_timing(False)
+    stats = torch.tensor([elapsed, float(paths), float(rays)], dtype=torch.float64, device=dev)
+    if distributed:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        paths, rays = int(sm[1]), int(sm[2])
+
+    if rank == 0:
+        finite = bool(torch.isfinite(image).all())
+        assert finite and float(image.mean()) > 0.0, "render produced no radiance"
+        assert paths == W * H * SPI * args.steps * world, (paths, W * H * SPI * args.steps * world)
+        out = {
+            "metric": "Mpaths/s", "value": paths / elapsed / 1e6, "unit": "Mpaths/s",
+            "mrays_per_s": rays / elapsed / 1e6,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"room.json {W}x{H}, {SPI} spp per GPU per step (one CLI iteration per GPU), "
+                                   "fov pi/4, depth 5, 10 nodes / 36 triangles / 2 spheres",
+                       "paths_per_step_per_gpu": W * H * SPI, "rays_per_path": rays / paths,
+                       "parallelism": f"sample-range x{world}" + (" + RCCL reduce(sum) to rank 0" if distributed else "")},
+        }
+        base = None
+        flops_per_ray = None
+        if not args.no_cpu_baseline:
+            base, flops_per_ray, _ = cpu_baseline(scene)
+            out["cpu_baseline"] = base
+        else:
+            out["cpu_baseline"] = None
+        # dominant kernel: k_bounce<false> (bounces 1..4), rank 0's launches
+        n_launch, ms = timing["k_bounce<false>"]
+        n0, ms0 = timing["k_bounce<true>"]
+        if n_launch and flops_per_ray is not None:
+            rays_rank0 = rays / world
+            paths_rank0 = paths / world
+            rays_next = rays_rank0 - paths_rank0           # rays cast by the k_bounce<false> launches
+            flops_per_launch = flops_per_ray * rays_next / n_launch
+            avg_ms = ms / n_launch
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            queue_bytes = (52 + 52) * rays_next / n_launch   # SoA ray record in + out
+            out["roofline"] = {
+                "bound": "valu", "kernel": "k_bounce<false>", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches": n_launch, "flops_per_ray": flops_per_ray,
+                "rays_per_launch": rays_next / n_launch,
+                "hbm_algorithmic_GBs": queue_bytes / (avg_ms * 1e-3) / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
+                "first_bounce_avg_ms": (ms0 / n0) if n0 else None,
+                "note": "no MFMA on this path; peak = fp32 vector FMA peak, while hit arithmetic is built unfused "
+                        "(-ffp-contract=off, bit-exact ids) so 78.6 T un-fused op/s is the reachable ceiling",
+            }
+        else:
+            out["roofline"] = None
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -233,6 +233,25 @@ int ptk_tonemap_dev(ptk_ctx* ctx, const float* image_rgb_dev, uint32_t* rgba8_de
 int ptk_get_counters(ptk_ctx* ctx, ptk_counters* out);
 int ptk_reset_counters(ptk_ctx* ctx);
 
+/* Per-kernel launch timing with HIP events on the context's stream (bench.py's
+ * roofline leg).  No reference counterpart (the reference only has wall-clock
+ * get_elapsed_time, abstract_pathtracer.cpp:133-137).  After enable(1) every
+ * kernel launch is bracketed by two events (at most 8192 launches are kept);
+ * ptk_get_timing synchronises, fills out[PTK_KERNEL_KINDS] and clears the log. */
+enum {
+    PTK_KERNEL_BOUNCE_FIRST = 0,    /* k_bounce<true>:  generate + cast + shade, bounce 0 */
+    PTK_KERNEL_BOUNCE_NEXT = 1,     /* k_bounce<false>: cast + shade, bounces 1..4        */
+    PTK_KERNEL_ACCUMULATE = 2,      /* k_accumulate                                       */
+    PTK_KERNEL_INTERSECT_BATCH = 3, /* k_intersect_batch                                  */
+    PTK_KERNEL_KINDS = 4
+};
+typedef struct ptk_kernel_timing {
+    uint64_t launches;
+    double total_ms;
+} ptk_kernel_timing;
+int ptk_ctx_enable_timing(ptk_ctx* ctx, int enable);
+int ptk_get_timing(ptk_ctx* ctx, ptk_kernel_timing* out /* [PTK_KERNEL_KINDS] */);
+
 /* Flattened KD-tree the context holds for mesh `mesh` (tests, diagnostics). */
 int ptk_scene_kd_info(ptk_ctx* ctx, uint32_t mesh, ptk_kd_info* info);
 

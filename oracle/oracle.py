@@ -28,6 +28,11 @@ def load():
         lib.orc_render_samples.restype = C.c_uint64
         lib.orc_render_samples.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64,
                                            C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
+        lib.orc_render_samples_stats.restype = C.c_uint64
+        lib.orc_render_samples_stats.argtypes = lib.orc_render_samples.argtypes + [C.c_void_p]
+        lib.orc_mt19937_nth.restype = C.c_uint32
+        lib.orc_mt19937_nth.argtypes = [C.c_uint32, C.c_uint32]
+        lib.orc_mt19937_floats.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         lib.orc_resolve_iteration.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         lib.orc_render_image.restype = C.c_uint64
         lib.orc_render_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64,
@@ -47,6 +52,10 @@ def load():
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
+
+
+STAT_NAMES = ["kd_box", "tri_a", "tri_b", "tri_full", "tri_hit", "sphere", "sphere_hit", "node", "node_hit", "ray",
+              "shade", "miss", "path", "mesh_win"]
 
 
 class OracleScene:
@@ -96,6 +105,14 @@ class OracleScene:
         rays = self._lib.orc_render_samples(self._h, w, h, float(np.float32(fov_y)), seed, pixel_begin, pixel_count,
                                             sample_begin, sample_count, out.ctypes.data, 1 if accumulate else 0, threads)
         return out, int(rays)
+
+    def render_samples_stats(self, w, h, fov_y, seed, sample_begin, sample_count, threads=1):
+        """(sum image, rays, {op name: count}) — operation counts for the flop model."""
+        out = np.zeros((h, w, 3), np.float32)
+        st = np.zeros(16, np.uint64)
+        rays = self._lib.orc_render_samples_stats(self._h, w, h, float(np.float32(fov_y)), seed, 0, w * h, sample_begin,
+                                                  sample_count, out.ctypes.data, 0, threads, st.ctypes.data)
+        return out, int(rays), {k: int(st[i]) for i, k in enumerate(STAT_NAMES)}
 
     def render_image(self, w, h, fov_y, seed, iterations, spi, threads=1):
         img = np.zeros((h, w, 3), np.float32)

@@ -33,6 +33,27 @@
 
 #include "../include/ptk.h"
 
+/* Dynamic operation counts for the algorithmic-flop model (bench.py). */
+enum {
+    ST_KD_BOX = 0,     /* bounding_box::intersect calls                      */
+    ST_TRI_A = 1,      /* triangles reaching the plane-side test             */
+    ST_TRI_B = 2,      /* ... passing distance >= 0 (cosine computed)        */
+    ST_TRI_FULL = 3,   /* ... passing cosine < 0 (projection + barycentrics) */
+    ST_TRI_HIT = 4,    /* ... inside the triangle                            */
+    ST_SPHERE = 5,     /* sphere::intersect calls                            */
+    ST_SPHERE_HIT = 6,
+    ST_NODE = 7,       /* ray -> node-local transforms                       */
+    ST_NODE_HIT = 8,   /* hits transformed back to world space               */
+    ST_RAY = 9,        /* scene::cast_ray calls                              */
+    ST_SHADE = 10,     /* rays that hit (material + bounce direction)        */
+    ST_MISS = 11,      /* rays that sampled the background                   */
+    ST_PATH = 12,      /* primary rays generated                             */
+    ST_MESH_WIN = 13,  /* rays whose closest hit is a triangle               */
+    ST_COUNT = 16
+};
+static __thread uint64_t* tl_stats = 0;
+#define STAT(i) do { if (tl_stats) tl_stats[i]++; } while (0)
+
 typedef struct { float x, y, z; } v3;
 typedef struct { float x, y; } v2;
 typedef struct { v3 o, d; } ray_t;
@@ -150,14 +171,18 @@ static inline hit_t tri_intersect(const ray_t* r, const tri_t* t)
 {
     hit_t res;
     res.hit = 0;
+    STAT(ST_TRI_A);
     const v3 l = sub3(r->o, P3(t->v[0].position));
     const float distance = dot3(l, t->n);
     if (distance < 0) return res;
+    STAT(ST_TRI_B);
     const float cosine = dot3(r->d, t->n);
     if (cosine >= 0) return res;
+    STAT(ST_TRI_FULL);
     const v3 projection = add3(r->o, scale3(r->d, distance / -cosine));
     const v3 bar = tri_baricentric(t, projection);
     if (bar.x >= 0 && bar.y >= 0 && bar.z >= 0) {
+        STAT(ST_TRI_HIT);
         res.hit = 1;
         res.position = projection;
         res.normal = normalize3(add3(add3(scale3(P3(t->v[0].normal), bar.x),
@@ -177,6 +202,7 @@ static void mesh_intersect_internal(const ray_t* r, const kd_node* node, hit_t* 
                                     uint64_t* stats)
 {
     if (stats) stats[0]++;
+    STAT(ST_KD_BOX);
     if (box_intersect(node->bmin, node->bmax, r)) {
         for (uint64_t i = 0; i < node->ntris; ++i) {
             if (stats) stats[1]++;
@@ -210,6 +236,7 @@ static hit_t sphere_intersect(const ray_t* r)
 {
     hit_t res;
     res.hit = 0;
+    STAT(ST_SPHERE);
     const float projection = dot3(sub3(V3(0.0f, 0.0f, 0.0f), r->o), r->d);
     const float sq_distance = dot3(r->o, r->o) - projection * projection;
     if (sq_distance > 1.0f) return res;
@@ -217,6 +244,7 @@ static hit_t sphere_intersect(const ray_t* r)
     const float t1 = projection - offset;
     const float t2 = projection + offset;
     if (t1 < 0 && t2 < 0) return res;
+    STAT(ST_SPHERE_HIT);
     res.hit = 1;
     res.position = add3(r->o, scale3(r->d, (t1 >= 0.0f ? t1 : t2)));
     res.normal = normalize3(res.position);
@@ -417,12 +445,15 @@ static hit_t scene_cast_ray(const orc_scene* s, const ray_t* r, int32_t* hit_nod
     hit_t best;
     best.hit = 0;
     *hit_node = -1;
+    STAT(ST_RAY);
     for (uint32_t i = 0; i < s->num_nodes; ++i) {
         const ptk_node_desc* nd = &s->nodes[i];
+        STAT(ST_NODE);
         const ray_t lr = ray_transform(nd->inv_transform, *r);
         hit_t r0 = (nd->shape_kind == PTK_SHAPE_SPHERE) ? sphere_intersect(&lr)
                                                         : mesh_intersect(&s->meshes[nd->mesh], &lr, stats);
         if (r0.hit) {
+            STAT(ST_NODE_HIT);
             r0.position = mat_mul_point(nd->transform, r0.position, 1.0f);
             r0.normal = normalize3(mat_mul_point(nd->normal_transform, r0.normal, 0.0f));
             const v3 dv = sub3(r0.position, r->o);
@@ -435,6 +466,7 @@ static hit_t scene_cast_ray(const orc_scene* s, const ray_t* r, int32_t* hit_nod
         }
     }
     if (dist2) *dist2 = distance;
+    if (best.hit) { STAT(ST_SHADE); if (best.prim >= 0) STAT(ST_MESH_WIN); } else STAT(ST_MISS);
     return best;
 }
 
@@ -661,6 +693,8 @@ typedef struct {
     float* sum;
     int accumulate;
     uint64_t rays;
+    int want_stats;
+    uint64_t stats[ST_COUNT];
 } sum_job;
 
 static void* sum_worker(void* arg)
@@ -668,6 +702,7 @@ static void* sum_worker(void* arg)
     sum_job* j = (sum_job*)arg;
     rng_t g;
     g.mode = 0;
+    tl_stats = j->want_stats ? j->stats : 0;
     for (uint64_t p = j->pixel_begin; p < j->pixel_end; ++p) {
         const uint32_t x = (uint32_t)(p % j->w), y = (uint32_t)(p / j->w);
         v3 color = V3(0.0f, 0.0f, 0.0f);
@@ -675,6 +710,7 @@ static void* sum_worker(void* arg)
             rng_begin_path(&g, j->seed, (uint32_t)p, j->sample_begin + k);
             const float u1 = rng_next(&g);
             const float u2 = rng_next(&g);
+            STAT(ST_PATH);
             const ray_t r = primary_ray(j->s, &j->view, j->w, j->h, x, y, u1, u2);
             color = add3(color, trace_recursive(j->s, r, PTK_MAX_DEPTH, &g, &j->rays));
         }
@@ -682,15 +718,40 @@ static void* sum_worker(void* arg)
         if (j->accumulate) { o[0] += color.x; o[1] += color.y; o[2] += color.z; }
         else { o[0] = color.x; o[1] = color.y; o[2] = color.z; }
     }
+    tl_stats = 0;
     return NULL;
 }
 
 /* Mirror of ptk_render_samples_dev: per-pixel SUM over a sample range, Philox RNG,
  * samples added in increasing sample index (abstract_pathtracer.cpp:70-86).
  * threads > 1 splits the pixel range (results do not depend on it). Returns rays cast. */
+static uint64_t render_samples_impl(const orc_scene* s, uint32_t w, uint32_t h, float fov_y, uint64_t seed,
+                                    uint64_t pixel_begin, uint64_t pixel_count, uint64_t sample_begin,
+                                    uint32_t sample_count, float* sum_rgb, int accumulate, int threads,
+                                    uint64_t* stats_out);
+
 uint64_t orc_render_samples(const orc_scene* s, uint32_t w, uint32_t h, float fov_y, uint64_t seed,
                             uint64_t pixel_begin, uint64_t pixel_count, uint64_t sample_begin,
                             uint32_t sample_count, float* sum_rgb, int accumulate, int threads)
+{
+    return render_samples_impl(s, w, h, fov_y, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb,
+                               accumulate, threads, NULL);
+}
+
+/* Same, also returning the ST_* operation counts (stats_out[ST_COUNT]). */
+uint64_t orc_render_samples_stats(const orc_scene* s, uint32_t w, uint32_t h, float fov_y, uint64_t seed,
+                                  uint64_t pixel_begin, uint64_t pixel_count, uint64_t sample_begin,
+                                  uint32_t sample_count, float* sum_rgb, int accumulate, int threads,
+                                  uint64_t* stats_out)
+{
+    return render_samples_impl(s, w, h, fov_y, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb,
+                               accumulate, threads, stats_out);
+}
+
+static uint64_t render_samples_impl(const orc_scene* s, uint32_t w, uint32_t h, float fov_y, uint64_t seed,
+                                    uint64_t pixel_begin, uint64_t pixel_count, uint64_t sample_begin,
+                                    uint32_t sample_count, float* sum_rgb, int accumulate, int threads,
+                                    uint64_t* stats_out)
 {
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > pixel_count) threads = pixel_count ? (int)pixel_count : 1;
@@ -704,6 +765,7 @@ uint64_t orc_render_samples(const orc_scene* s, uint32_t w, uint32_t h, float fo
         jobs[i].pixel_end = pixel_begin + pixel_count * (uint64_t)(i + 1) / (uint64_t)threads;
         jobs[i].sample_begin = sample_begin; jobs[i].sample_count = sample_count;
         jobs[i].sum = sum_rgb; jobs[i].accumulate = accumulate;
+        jobs[i].want_stats = stats_out != NULL;
     }
     if (threads == 1) sum_worker(&jobs[0]);
     else {
@@ -712,6 +774,11 @@ uint64_t orc_render_samples(const orc_scene* s, uint32_t w, uint32_t h, float fo
     }
     uint64_t rays = 0;
     for (int i = 0; i < threads; ++i) rays += jobs[i].rays;
+    if (stats_out) {
+        memset(stats_out, 0, ST_COUNT * sizeof(uint64_t));
+        for (int i = 0; i < threads; ++i)
+            for (int k = 0; k < ST_COUNT; ++k) stats_out[k] += jobs[i].stats[k];
+    }
     free(jobs);
     free(th);
     return rays;
@@ -906,4 +973,25 @@ void orc_secondary_rays(const orc_scene* s, uint32_t w, uint32_t h, float fov_y,
         o[i] = rr.o.x; o[n + i] = rr.o.y; o[2 * n + i] = rr.o.z;
         d[i] = rr.d.x; d[n + i] = rr.d.y; d[2 * n + i] = rr.d.z;
     }
+}
+
+/* n-th (1-based) output of std::mt19937 seeded with `seed` — known-answer hook
+ * (the C++ standard fixes the 10000th output of the default-seeded engine). */
+uint32_t orc_mt19937_nth(uint32_t seed, uint32_t n)
+{
+    rng_t g;
+    g.mode = 1;
+    mt_seed(&g, seed);
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < n; ++i) v = mt_next_u32(&g);
+    return v;
+}
+
+/* rng::next() of the mt19937 mode: libstdc++ uniform_real_distribution<float>. */
+void orc_mt19937_floats(uint32_t seed, uint32_t n, float* out)
+{
+    rng_t g;
+    g.mode = 1;
+    mt_seed(&g, seed);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng_next(&g);
 }

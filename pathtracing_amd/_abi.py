@@ -102,6 +102,12 @@ class Counters(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64)]
 
 
+class KernelTiming(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+PTK_KERNEL_NAMES = ["k_bounce<true>", "k_bounce<false>", "k_accumulate", "k_intersect_batch"]
+
 # name -> (restype, argtypes); every symbol include/ptk.h declares.
 SYMBOLS = {
     "ptk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -121,6 +127,8 @@ SYMBOLS = {
     "ptk_tonemap_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ptk_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "ptk_reset_counters": (C.c_int, [C.c_void_p]),
+    "ptk_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ptk_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ptk_scene_kd_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(KdInfo)]),
 }
 

@@ -326,6 +326,14 @@ struct ptk_ctx {
     float* d_sample_L = nullptr;
     uint32_t* d_seg_count = nullptr;
     unsigned long long* d_counters = nullptr;
+
+    // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
+    bool timing = false;
+    struct Stamp {
+        int kind;
+        hipEvent_t a, b;
+    };
+    std::vector<Stamp> stamps;
 };
 
 namespace {
@@ -411,6 +419,41 @@ void make_shade_record(const ptk_triangle& t, float4* s)
     s[3] = make_float4(t.v[1].uv[1], t.v[2].uv[0], t.v[2].uv[1], 0.0f);
 }
 
+constexpr size_t kMaxStamps = 8192;
+
+// Brackets one kernel launch with HIP events on the context's stream when timing is on.
+struct LaunchTimer {
+    ptk_ctx* c;
+    ptk_ctx::Stamp st{};
+    bool on = false;
+    LaunchTimer(ptk_ctx* ctx, int kind) : c(ctx)
+    {
+        if (!c->timing || c->stamps.size() >= kMaxStamps) return;
+        if (hipEventCreate(&st.a) != hipSuccess) return;
+        if (hipEventCreate(&st.b) != hipSuccess) {
+            (void)hipEventDestroy(st.a);
+            return;
+        }
+        st.kind = kind;
+        on = hipEventRecord(st.a, c->stream) == hipSuccess;
+    }
+    ~LaunchTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(st.b, c->stream);
+        c->stamps.push_back(st);
+    }
+};
+
+void drop_stamps(ptk_ctx* c)
+{
+    for (auto& s : c->stamps) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    c->stamps.clear();
+}
+
 int set_device(ptk_ctx* c)
 {
     PTK_HIP(c, hipSetDevice(c->device));
@@ -452,6 +495,7 @@ void ptk_ctx_destroy(ptk_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     free_render(c);
+    drop_stamps(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -650,8 +694,11 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
     if (n > 0x7FFFFFFFull * kBlock) return fail(c, PTK_ERR_INVALID, "ptk_intersect_batch: batch too large");
     if (int r = set_device(c)) return r;
     const uint32_t blocks = (uint32_t)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_intersect_batch, dim3(blocks), dim3(kBlock), 0, c->stream, c->S, n, o, d, node, prim, t, u, v,
-                       position, normal, uv);
+    {
+        LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
+        hipLaunchKernelGGL(k_intersect_batch, dim3(blocks), dim3(kBlock), 0, c->stream, c->S, n, o, d, node, prim, t, u,
+                           v, position, normal, uv);
+    }
     PTK_HIP(c, hipGetLastError());
     return PTK_OK;
 }
@@ -777,14 +824,21 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
             A.sample_begin = sample_begin + s0;
             A.seed = seed;
             A.bounce = 0;
-            k_bounce<true><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+            {
+                LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
+                k_bounce<true><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+            }
             for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) {
                 A.bounce = b;
+                LaunchTimer lt(c, PTK_KERNEL_BOUNCE_NEXT);
                 k_bounce<false><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
             }
             const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
-            hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, c->d_sample_L, cap,
-                               (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
+            {
+                LaunchTimer lt(c, PTK_KERNEL_ACCUMULATE);
+                hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, c->d_sample_L, cap,
+                                   (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
+            }
             const uint32_t entries = A.num_segments * (PTK_MAX_DEPTH - 1);
             const uint32_t tally_blocks = entries / (kBlock * 8) + 1 > 256u ? 256u : entries / (kBlock * 8) + 1;
             hipLaunchKernelGGL(k_tally, dim3(tally_blocks), dim3(kBlock), 0, c->stream,
@@ -858,6 +912,32 @@ int ptk_get_counters(ptk_ctx* c, ptk_counters* out)
     PTK_HIP(c, hipStreamSynchronize(c->stream));
     out->paths = h[0];
     out->rays = h[1];
+    return PTK_OK;
+}
+
+int ptk_ctx_enable_timing(ptk_ctx* c, int enable)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    drop_stamps(c);
+    c->timing = enable != 0;
+    return PTK_OK;
+}
+
+int ptk_get_timing(ptk_ctx* c, ptk_kernel_timing* out)
+{
+    if (!c || !out) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memset(out, 0, sizeof(ptk_kernel_timing) * PTK_KERNEL_KINDS);
+    for (auto& s : c->stamps) {
+        float ms = 0.0f;
+        PTK_HIP(c, hipEventElapsedTime(&ms, s.a, s.b));
+        out[s.kind].launches += 1;
+        out[s.kind].total_ms += ms;
+    }
+    drop_stamps(c);
     return PTK_OK;
 }
 

@@ -122,6 +122,15 @@ class Context:
         self._check(self._lib.ptk_get_counters(self._h, C.byref(c)))
         return int(c.paths), int(c.rays)
 
+    def enable_timing(self, on=True):
+        self._check(self._lib.ptk_ctx_enable_timing(self._h, 1 if on else 0))
+
+    def timing(self):
+        """{kernel name: (launches, total_ms)} since enable_timing / the last call."""
+        arr = (_abi.KernelTiming * len(_abi.PTK_KERNEL_NAMES))()
+        self._check(self._lib.ptk_get_timing(self._h, C.cast(arr, C.c_void_p)))
+        return {n: (int(arr[i].launches), float(arr[i].total_ms)) for i, n in enumerate(_abi.PTK_KERNEL_NAMES)}
+
     def reset_counters(self):
         self._check(self._lib.ptk_reset_counters(self._h))
 

@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal", type=int, default=None, help="PTK_OPT_TRAVERSAL override (0/1), for A/B runs")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +97,8 @@ def main():
     ctx = Context(local_rank)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
+    if args.traversal is not None:
+        ctx.set_option(1, args.traversal)
     ctx.upload(scene)
     ctx.render_begin(W, H, FOV)
     total = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)

@@ -233,6 +233,15 @@ int ptk_tonemap_dev(ptk_ctx* ctx, const float* image_rgb_dev, uint32_t* rgba8_de
 int ptk_get_counters(ptk_ctx* ctx, ptk_counters* out);
 int ptk_reset_counters(ptk_ctx* ctx);
 
+/* Tuning switches (results are identical for every value; tests run both).
+ * PTK_OPT_TRAVERSAL: how scene::cast_ray's node loop (scene.cpp:361-395) is mapped to a
+ * wave: 0 = every lane walks every mesh node's triangles together; 1 = meshes are root-box
+ * tested in the uniform loop and each lane then visits only the nodes whose box it pierced;
+ * 2 (default) = 0 for the coherent primary rays of bounce 0, 1 for later bounces and for
+ * ptk_intersect_batch.  No reference counterpart. */
+enum { PTK_OPT_TRAVERSAL = 1 };
+int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
+
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's
  * roofline leg).  No reference counterpart (the reference only has wall-clock
  * get_elapsed_time, abstract_pathtracer.cpp:133-137).  After enable(1) every

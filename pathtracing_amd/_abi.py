@@ -106,6 +106,7 @@ class KernelTiming(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double)]
 
 
+PTK_OPT_TRAVERSAL = 1
 PTK_KERNEL_NAMES = ["k_bounce<true>", "k_bounce<false>", "k_accumulate", "k_intersect_batch"]
 
 # name -> (restype, argtypes); every symbol include/ptk.h declares.
@@ -127,6 +128,7 @@ SYMBOLS = {
     "ptk_tonemap_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ptk_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "ptk_reset_counters": (C.c_int, [C.c_void_p]),
+    "ptk_ctx_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ptk_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ptk_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ptk_scene_kd_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(KdInfo)]),

@@ -39,6 +39,7 @@ constexpr uint64_t kDefaultMaxPaths = 1ull << 24;
 
 // ------------------------------------------------------------------ kernels
 
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_intersect_batch(const DScene S, uint64_t n, const float* __restrict__ o,
                                                             const float* __restrict__ d, int32_t* __restrict__ node,
                                                             int32_t* __restrict__ prim, float* __restrict__ t,
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch(const DScene S, uint
     const V3 ro = mk(o[j], o[n + j], o[2 * n + j]);
     const V3 rd = mk(d[j], d[n + j], d[2 * n + j]);
     Hit h;
-    intersect_scene(S, ro, rd, on, h);
+    intersect_scene_mode<MODE>(S, ro, rd, on, h);
     if (!on) return;
     V3 nw = mk(0.0f, 0.0f, 0.0f);
     float uvx = 0.0f, uvy = 0.0f, uu = 0.0f, vv = 0.0f;
@@ -94,7 +95,7 @@ struct BounceArgs {
     uint32_t bounce;
 };
 
-template <bool FIRST>
+template <bool FIRST, int MODE>
 __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V, const BounceArgs A)
 {
     __shared__ uint32_t wave_count[kBlock / 64];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
     }
 
     Hit h;
-    intersect_scene(S, o, d, on, h);
+    intersect_scene_mode<MODE>(S, o, d, on, h);
 
     bool alive = false;
     if (on) {
@@ -326,6 +327,8 @@ struct ptk_ctx {
     float* d_sample_L = nullptr;
     uint32_t* d_seg_count = nullptr;
     unsigned long long* d_counters = nullptr;
+
+    int traversal = 2; // PTK_OPT_TRAVERSAL
 
     // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
     bool timing = false;
@@ -696,8 +699,10 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
     const uint32_t blocks = (uint32_t)((n + kBlock - 1) / kBlock);
     {
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
-        hipLaunchKernelGGL(k_intersect_batch, dim3(blocks), dim3(kBlock), 0, c->stream, c->S, n, o, d, node, prim, t, u,
-                           v, position, normal, uv);
+        if (c->traversal >= 1)
+            k_intersect_batch<1><<<dim3(blocks), dim3(kBlock), 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv);
+        else
+            k_intersect_batch<0><<<dim3(blocks), dim3(kBlock), 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv);
     }
     PTK_HIP(c, hipGetLastError());
     return PTK_OK;
@@ -826,12 +831,14 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
             A.bounce = 0;
             {
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
-                k_bounce<true><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+                if (c->traversal == 1) k_bounce<true, 1><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+                else k_bounce<true, 0><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
             }
             for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) {
                 A.bounce = b;
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_NEXT);
-                k_bounce<false><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+                if (c->traversal >= 1) k_bounce<false, 1><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+                else k_bounce<false, 0><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
             }
             const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
             {
@@ -913,6 +920,16 @@ int ptk_get_counters(ptk_ctx* c, ptk_counters* out)
     out->paths = h[0];
     out->rays = h[1];
     return PTK_OK;
+}
+
+int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (option == PTK_OPT_TRAVERSAL && value >= 0 && value <= 2) {
+        c->traversal = value;
+        return PTK_OK;
+    }
+    return fail(c, PTK_ERR_INVALID, "ptk_ctx_set_option: unknown option or value");
 }
 
 int ptk_ctx_enable_timing(ptk_ctx* c, int enable)

@@ -294,6 +294,138 @@ __device__ __forceinline__ void intersect_scene(const DScene& S, V3 o, V3 d, boo
     }
 }
 
+// ---- traversal mode 1: per-lane node lists ------------------------------------
+// In scenes like Room every ray tests every node, but a ray pierces the root box
+// of only ~1.4 of the 8 mesh nodes, so walking each mesh's triangles with the whole
+// wave (mode 0) leaves most lanes idle.  Mode 1 splits cast_ray in two phases:
+//   1. wave-uniform node loop: ray -> local, spheres intersected in place, meshes
+//      only root-box tested; a per-lane bit mask records the meshes to visit;
+//   2. per-lane loop over that mask: every lane takes ITS next mesh node, rebuilds
+//      the same local ray (same operations, same bits) and traverses it.
+// The reference's "first node wins exact ties" (strict < in node order,
+// scene.cpp:386) is kept by an explicit (d0, node index) comparison, so the result
+// does not depend on the processing order.
+
+__device__ __forceinline__ void best_update(Hit& best, float d0, int n, int prim, V3 a, V3 pw)
+{
+    if (d0 < best.d0 || (d0 == best.d0 && n < best.node)) {
+        best.d0 = d0;
+        best.node = n;
+        best.prim = prim;
+        best.a0 = a.x;
+        best.a1 = a.y;
+        best.a2 = a.z;
+        best.pw = pw;
+    }
+}
+
+// One leaf's triangles, per-lane addresses (scene.cpp:192-203).
+__device__ __forceinline__ void leaf_triangles(const DScene& S, uint32_t first, uint32_t count, V3 o, V3 d,
+                                               float& best_d, bool& found, int& prim_out, V3& bar_out, V3& p_out)
+{
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4* t = S.tri_hit + (size_t)(first + k) * 4;
+        const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
+        if (tri_test(q0, q1, q2, q3, o, d, best_d, bar_out, p_out)) {
+            prim_out = (int)(first + k);
+            found = true;
+        }
+    }
+}
+
+// mesh::intersect for a lane whose root-box test already passed (scene.cpp:190).
+__device__ __forceinline__ bool mesh_traverse_lane(const DScene& S, const DMesh mesh, V3 o, V3 d, bool work,
+                                                   int& prim_out, V3& bar_out, V3& p_out)
+{
+    float best_d = 3.402823466e+38f;
+    bool found = false;
+    const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
+    uint32_t i = mesh.kd_count;
+    if (work) {
+        const float4 r0 = reinterpret_cast<const float4*>(kd)[0];
+        const float4 r1 = reinterpret_cast<const float4*>(kd)[1];
+        const uint32_t a = __float_as_uint(r0.w), b = __float_as_uint(r1.w);
+        if (b != 0u) leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, found, prim_out, bar_out, p_out);
+        i = 1u; // root hit: continue with its first child (a leaf root has kd_count == 1)
+    }
+    while (i < mesh.kd_count) {
+        const float4 n0 = reinterpret_cast<const float4*>(kd + i)[0];
+        const float4 n1 = reinterpret_cast<const float4*>(kd + i)[1];
+        const uint32_t a = __float_as_uint(n0.w);
+        const uint32_t b = __float_as_uint(n1.w);
+        const bool hit = box_intersect(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, o, d);
+        if (hit && b != 0u) leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, found, prim_out, bar_out, p_out);
+        i = (hit || b != 0u) ? i + 1u : a;
+    }
+    return found;
+}
+
+__device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
+{
+    best.d0 = 3.402823466e+38f;
+    best.node = -1;
+    best.prim = -1;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    best.pw = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t g = 0; g < S.num_nodes; g += 32u) {
+        const uint32_t gend = (S.num_nodes - g < 32u) ? S.num_nodes : g + 32u;
+        uint32_t pending = 0u;
+        // phase 1: wave-uniform
+        for (uint32_t n = g; n < gend; ++n) {
+            const DNode* __restrict__ nd = S.nodes + n;
+            const V3 lo = mat_point(nd->inv, o, 1.0f);
+            const V3 ld = normalize(mat_point(nd->inv, d, 0.0f));
+            if (nd->kind == PTK_SHAPE_SPHERE) {
+                V3 p = mk(0.0f, 0.0f, 0.0f);
+                if (lane_on && sphere_intersect(lo, ld, p)) {
+                    const V3 pw = mat_point(nd->xf, p, 1.0f);
+                    const V3 dv = pw - o;
+                    best_update(best, dot(dv, dv), (int)n, -1, p, pw);
+                }
+            } else {
+                const DMesh mesh = S.meshes[nd->mesh];
+                const DKdNode kn = S.kd[mesh.kd_base];
+                const bool inside = lane_on && box_intersect(kn.bmin[0], kn.bmin[1], kn.bmin[2], kn.bmax[0],
+                                                             kn.bmax[1], kn.bmax[2], lo, ld);
+                pending |= inside ? (1u << (n - g)) : 0u;
+            }
+        }
+        // phase 2: per-lane node list
+        while (__builtin_amdgcn_ballot_w64(pending != 0u) != 0ull) {
+            const bool work = pending != 0u;
+            const uint32_t n = g + (work ? (uint32_t)__builtin_ctz(pending) : 0u);
+            pending &= pending - 1u;
+            const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + n);
+            const float4 i0 = nv[0], i1 = nv[1], i2 = nv[2], i3 = nv[3];
+            const V3 lo = mk((i0.x * o.x + i1.x * o.y) + (i2.x * o.z + i3.x * 1.0f),
+                             (i0.y * o.x + i1.y * o.y) + (i2.y * o.z + i3.y * 1.0f),
+                             (i0.z * o.x + i1.z * o.y) + (i2.z * o.z + i3.z * 1.0f));
+            const V3 ld = normalize(mk((i0.x * d.x + i1.x * d.y) + (i2.x * d.z + i3.x * 0.0f),
+                                       (i0.y * d.x + i1.y * d.y) + (i2.y * d.z + i3.y * 0.0f),
+                                       (i0.z * d.x + i1.z * d.y) + (i2.z * d.z + i3.z * 0.0f)));
+            const uint32_t mesh_idx = work ? (S.nodes + n)->mesh : 0u;
+            const DMesh mesh = S.meshes[mesh_idx];
+            int prim = -1;
+            V3 p = mk(0.0f, 0.0f, 0.0f), a = mk(0.0f, 0.0f, 0.0f);
+            if (mesh_traverse_lane(S, mesh, lo, ld, work, prim, a, p)) {
+                const float4 x0 = nv[4], x1 = nv[5], x2 = nv[6], x3 = nv[7];
+                const V3 pw = mk((x0.x * p.x + x1.x * p.y) + (x2.x * p.z + x3.x * 1.0f),
+                                 (x0.y * p.x + x1.y * p.y) + (x2.y * p.z + x3.y * 1.0f),
+                                 (x0.z * p.x + x1.z * p.y) + (x2.z * p.z + x3.z * 1.0f));
+                const V3 dv = pw - o;
+                best_update(best, dot(dv, dv), (int)n, prim, a, pw);
+            }
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
+{
+    if (MODE == 1) intersect_scene_lanelist(S, o, d, lane_on, best);
+    else intersect_scene(S, o, d, lane_on, best);
+}
+
 // Rebuilds raycast_result::normal / uv for the winning hit only (the reference
 // computes them for every candidate, scene.cpp:173-182,433-437; the values for
 // the winner are identical).  n_world: scene.cpp:378.

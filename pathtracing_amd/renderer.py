@@ -122,6 +122,9 @@ class Context:
         self._check(self._lib.ptk_get_counters(self._h, C.byref(c)))
         return int(c.paths), int(c.rays)
 
+    def set_option(self, option, value):
+        self._check(self._lib.ptk_ctx_set_option(self._h, option, value))
+
     def enable_timing(self, on=True):
         self._check(self._lib.ptk_ctx_enable_timing(self._h, 1 if on else 0))
 

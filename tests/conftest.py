@@ -41,12 +41,21 @@ def get_oracle(name):
 
 
 @pytest.fixture(scope="session")
-def gpu_ctx():
-    """One ptk context on cuda:0 for the whole GPU session (the HIP library must load: no fallback)."""
+def _gpu_ctx_session():
     from pathtracing_amd import Context
     ctx = Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(params=[2, 1, 0], ids=["mixed", "lanelist", "uniform"])
+def gpu_ctx(request, _gpu_ctx_session):
+    """One ptk context on cuda:0 for the whole GPU session (the HIP library must load: no fallback);
+    every GPU test runs under both PTK_OPT_TRAVERSAL values."""
+    from pathtracing_amd import _abi
+    _gpu_ctx_session.set_option(_abi.PTK_OPT_TRAVERSAL, request.param)
+    yield _gpu_ctx_session
+    _gpu_ctx_session.set_option(_abi.PTK_OPT_TRAVERSAL, 2)
 
 
 def random_soup(n_tris, seed, extent=1.0, size=0.08):

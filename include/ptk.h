@@ -174,6 +174,13 @@ int ptk_scene_set_camera(ptk_ctx* ctx, const ptk_camera_desc* camera);
 int ptk_kd_build(const ptk_triangle* triangles, uint64_t num_triangles,
                  ptk_kd_info* info, ptk_kd_node* nodes, uint64_t nodes_cap,
                  uint32_t* prims, uint64_t prims_cap);
+/* The public kd_tree_node constructor (scene.h:159, scene.cpp:214): the caller supplies
+ * the root box (bounds = {min xyz, max xyz}) and the depth of the root, which selects the
+ * first split axis (depth % 3) and counts towards PTK_KD_MAX_DEPTH. */
+int ptk_kd_build_bounded(const ptk_triangle* triangles, uint64_t num_triangles,
+                         const float bounds[6], uint32_t root_depth,
+                         ptk_kd_info* info, ptk_kd_node* nodes, uint64_t nodes_cap,
+                         uint32_t* prims, uint64_t prims_cap);
 
 /* ---- closest hit for caller-supplied rays (parity entry) -----------------
  * scene::cast_ray (scene.cpp:355-399) for n rays.  SoA device arrays:
@@ -260,6 +267,18 @@ typedef struct ptk_kernel_timing {
 } ptk_kernel_timing;
 int ptk_ctx_enable_timing(ptk_ctx* ctx, int enable);
 int ptk_get_timing(ptk_ctx* ctx, ptk_kernel_timing* out /* [PTK_KERNEL_KINDS] */);
+
+/* ---- device buffers for hosts without a HIP runtime of their own --------------
+ * The C++ rt:: mirror (pathtracing_amd/host) is plain g++ code: it gets the sum / image
+ * buffers that ptk_render_samples_dev and ptk_resolve_iteration_dev work on from here.
+ * No reference counterpart (the reference keeps its image in host memory,
+ * abstract_pathtracer.cpp:18).  memset is enqueued on the context's stream; download
+ * and upload synchronise it. */
+int ptk_dev_alloc(ptk_ctx* ctx, uint64_t bytes, void** out_dev);
+int ptk_dev_free(ptk_ctx* ctx, void* dev);
+int ptk_dev_memset(ptk_ctx* ctx, void* dev, int value, uint64_t bytes);
+int ptk_dev_download(ptk_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
+int ptk_dev_upload(ptk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes);
 
 /* Flattened KD-tree the context holds for mesh `mesh` (tests, diagnostics). */
 int ptk_scene_kd_info(ptk_ctx* ctx, uint32_t mesh, ptk_kd_info* info);

@@ -119,6 +119,8 @@ SYMBOLS = {
     "ptk_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "ptk_scene_set_camera": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc)]),
     "ptk_kd_build": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(KdInfo), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "ptk_kd_build_bounded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(KdInfo), C.c_void_p, C.c_uint64,
+                                      C.c_void_p, C.c_uint64]),
     "ptk_intersect_batch_dev": (C.c_int, [C.c_void_p, C.c_uint64] + [C.c_void_p] * 10),
     "ptk_intersect_batch": (C.c_int, [C.c_void_p, C.c_uint64] + [C.c_void_p] * 10),
     "ptk_render_begin": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64]),
@@ -131,6 +133,11 @@ SYMBOLS = {
     "ptk_ctx_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ptk_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ptk_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ptk_dev_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ptk_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ptk_dev_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]),
+    "ptk_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ptk_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ptk_scene_kd_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(KdInfo)]),
 }
 

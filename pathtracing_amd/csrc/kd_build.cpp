@@ -99,7 +99,28 @@ void build(Builder& b, std::vector<uint32_t>& idx, const float* bmin, const floa
 
 } // namespace
 
-// Internal C++ entry used by ptk.hip as well.
+// Internal C++ entries used by ptk.hip as well.
+void ptk_kd_build_vectors_bounded(const ptk_triangle* triangles, uint64_t num_triangles, const float* bmin,
+                                  const float* bmax, uint32_t root_depth, ptk_kd_info* info,
+                                  std::vector<ptk_kd_node>& nodes, std::vector<uint32_t>& prims)
+{
+    Builder b;
+    b.tris = triangles;
+    std::vector<uint32_t> idx(num_triangles);
+    for (uint64_t i = 0; i < num_triangles; ++i) idx[i] = static_cast<uint32_t>(i);
+    build(b, idx, bmin, bmax, root_depth);
+    if (info) {
+        info->num_nodes = static_cast<uint32_t>(b.nodes.size());
+        info->num_leaves = b.leaves;
+        info->num_leaf_prims = b.prims.size();
+        info->max_depth = b.max_depth;
+        std::memcpy(info->bmin, bmin, 12);
+        std::memcpy(info->bmax, bmax, 12);
+    }
+    nodes.swap(b.nodes);
+    prims.swap(b.prims);
+}
+
 void ptk_kd_build_vectors(const ptk_triangle* triangles, uint64_t num_triangles, ptk_kd_info* info,
                           std::vector<ptk_kd_node>& nodes, std::vector<uint32_t>& prims)
 {
@@ -113,32 +134,13 @@ void ptk_kd_build_vectors(const ptk_triangle* triangles, uint64_t num_triangles,
                 bmin[k] = (p < bmin[k]) ? p : bmin[k];
                 bmax[k] = (bmax[k] < p) ? p : bmax[k];
             }
-    Builder b;
-    b.tris = triangles;
-    std::vector<uint32_t> idx(num_triangles);
-    for (uint64_t i = 0; i < num_triangles; ++i) idx[i] = static_cast<uint32_t>(i);
-    build(b, idx, bmin, bmax, 0);
-    if (info) {
-        info->num_nodes = static_cast<uint32_t>(b.nodes.size());
-        info->num_leaves = b.leaves;
-        info->num_leaf_prims = b.prims.size();
-        info->max_depth = b.max_depth;
-        std::memcpy(info->bmin, bmin, 12);
-        std::memcpy(info->bmax, bmax, 12);
-    }
-    nodes.swap(b.nodes);
-    prims.swap(b.prims);
+    ptk_kd_build_vectors_bounded(triangles, num_triangles, bmin, bmax, 0, info, nodes, prims);
 }
 
-extern "C" int ptk_kd_build(const ptk_triangle* triangles, uint64_t num_triangles, ptk_kd_info* info,
-                            ptk_kd_node* nodes, uint64_t nodes_cap, uint32_t* prims, uint64_t prims_cap)
+namespace {
+int copy_out(const ptk_kd_info& local, const std::vector<ptk_kd_node>& n, const std::vector<uint32_t>& p,
+             ptk_kd_info* info, ptk_kd_node* nodes, uint64_t nodes_cap, uint32_t* prims, uint64_t prims_cap)
 {
-    if (!triangles && num_triangles) return PTK_ERR_INVALID;
-    if (num_triangles > 0xFFFFFFFFull / 4) return PTK_ERR_INVALID;
-    std::vector<ptk_kd_node> n;
-    std::vector<uint32_t> p;
-    ptk_kd_info local;
-    ptk_kd_build_vectors(triangles, num_triangles, &local, n, p);
     if (info) *info = local;
     if (nodes) {
         if (nodes_cap < n.size()) return PTK_ERR_INVALID;
@@ -149,4 +151,30 @@ extern "C" int ptk_kd_build(const ptk_triangle* triangles, uint64_t num_triangle
         std::memcpy(prims, p.data(), p.size() * sizeof(uint32_t));
     }
     return PTK_OK;
+}
+} // namespace
+
+extern "C" int ptk_kd_build(const ptk_triangle* triangles, uint64_t num_triangles, ptk_kd_info* info,
+                            ptk_kd_node* nodes, uint64_t nodes_cap, uint32_t* prims, uint64_t prims_cap)
+{
+    if (!triangles && num_triangles) return PTK_ERR_INVALID;
+    if (num_triangles > 0xFFFFFFFFull / 4) return PTK_ERR_INVALID;
+    std::vector<ptk_kd_node> n;
+    std::vector<uint32_t> p;
+    ptk_kd_info local;
+    ptk_kd_build_vectors(triangles, num_triangles, &local, n, p);
+    return copy_out(local, n, p, info, nodes, nodes_cap, prims, prims_cap);
+}
+
+extern "C" int ptk_kd_build_bounded(const ptk_triangle* triangles, uint64_t num_triangles, const float bounds[6],
+                                    uint32_t root_depth, ptk_kd_info* info, ptk_kd_node* nodes, uint64_t nodes_cap,
+                                    uint32_t* prims, uint64_t prims_cap)
+{
+    if ((!triangles && num_triangles) || !bounds) return PTK_ERR_INVALID;
+    if (num_triangles > 0xFFFFFFFFull / 4 || root_depth > PTK_KD_MAX_DEPTH) return PTK_ERR_INVALID;
+    std::vector<ptk_kd_node> n;
+    std::vector<uint32_t> p;
+    ptk_kd_info local;
+    ptk_kd_build_vectors_bounded(triangles, num_triangles, bounds, bounds + 3, root_depth, &local, n, p);
+    return copy_out(local, n, p, info, nodes, nodes_cap, prims, prims_cap);
 }

@@ -958,6 +958,56 @@ int ptk_get_timing(ptk_ctx* c, ptk_kernel_timing* out)
     return PTK_OK;
 }
 
+int ptk_dev_alloc(ptk_ctx* c, uint64_t bytes, void** out)
+{
+    if (!c || !out) return PTK_ERR_INVALID;
+    *out = nullptr;
+    if (int r = set_device(c)) return r;
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) return fail(c, PTK_ERR_NOMEM, "ptk_dev_alloc: out of device memory");
+    if (e != hipSuccess) return fail(c, PTK_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *out = p;
+    return PTK_OK;
+}
+
+int ptk_dev_free(ptk_ctx* c, void* p)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!p) return PTK_OK;
+    if (int r = set_device(c)) return r;
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    PTK_HIP(c, hipFree(p));
+    return PTK_OK;
+}
+
+int ptk_dev_memset(ptk_ctx* c, void* p, int value, uint64_t bytes)
+{
+    if (!c || (!p && bytes)) return PTK_ERR_INVALID;
+    if (bytes == 0) return PTK_OK;
+    if (int r = set_device(c)) return r;
+    PTK_HIP(c, hipMemsetAsync(p, value, bytes, c->stream));
+    return PTK_OK;
+}
+
+int ptk_dev_download(ptk_ctx* c, void* dst, const void* src, uint64_t bytes)
+{
+    if (!c || ((!dst || !src) && bytes)) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    if (bytes) PTK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_dev_upload(ptk_ctx* c, void* dst, const void* src, uint64_t bytes)
+{
+    if (!c || ((!dst || !src) && bytes)) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    if (bytes) PTK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
 int ptk_reset_counters(ptk_ctx* c)
 {
     if (!c) return PTK_ERR_INVALID;

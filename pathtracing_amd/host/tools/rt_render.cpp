@@ -1,0 +1,229 @@
+// rt_render — a caller written purely against the reference-shaped rt:: API, used to show
+// (and test) that the API drives the GPU path end to end.  It plays the role of the
+// reference's CLI (src/CLI/main.cpp): build an rt::scene the way scene_loader.cpp does
+// (translate -> multiply(Rz*Ry*Rx) -> scale; shared meshes and samplers), call
+// rt::pathtracer::run, subscribe to the events, wait(), save the result.
+//
+// Input is a small token stream ("ptkscene 1", written by tests/host_scene_text.py from
+// the same scene objects the Python tests use) rather than the reference's JSON + OBJ
+// files: those loaders are callers of the path, not part of it.
+//
+//   rt_render --scene S --out image.bin [--resolution W H]
+//             [--iterations N] [--spp-per-iteration K] [--seed X] [--device D] [--threads T]
+//             [--ldr-out rgba8.bin] [--interrupt-after N]
+//
+// image.bin: W*H*3 little-endian floats, row 0 = top (linear HDR, before the CLI tone map).
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include <pathtracer.h>
+
+namespace {
+
+bool fail(const std::string& msg)
+{
+    std::fprintf(stderr, "rt_render: %s\n", msg.c_str());
+    return false;
+}
+
+float next_float(std::istream& in)
+{
+    std::string tok;
+    in >> tok;
+    return std::strtof(tok.c_str(), nullptr); // accepts %a hex floats: values round-trip exactly
+}
+
+glm::vec3 next_vec3(std::istream& in)
+{
+    const float x = next_float(in), y = next_float(in), z = next_float(in);
+    return { x, y, z };
+}
+
+bool load_scene_text(const std::string& path, rt::scene& scene)
+{
+    std::ifstream in(path);
+    if (!in) return fail("cannot open " + path);
+    std::string tok;
+    int version = 0;
+    in >> tok >> version;
+    if (tok != "ptkscene" || version != 1) return fail("not a ptkscene 1 file");
+
+    std::map<std::string, std::shared_ptr<rt::image>> textures;
+    std::map<std::string, std::shared_ptr<rt::sampler_2d>> samplers;
+    std::map<std::string, std::shared_ptr<rt::color_sampler>> colors;
+    std::map<std::string, std::shared_ptr<rt::mesh>> meshes;
+
+    while (in >> tok) {
+        if (tok == "end") return true;
+        if (tok == "camera") {
+            scene.camera.position = next_vec3(in);
+            scene.camera.set_direction(next_vec3(in));
+        } else if (tok == "texture") {
+            std::string id, file, mode;
+            int ldr = 0;
+            in >> id >> file >> mode >> ldr;
+            auto img = std::make_shared<rt::image>();
+            img->load(file);
+            if (img->get_width() == 0) return fail("texture " + file + " did not load");
+            if (ldr) img->to_ldr();
+            img->sample_mode = mode == "nearest" ? rt::sample_mode::nearest : rt::sample_mode::linear;
+            textures[id] = img;
+        } else if (tok == "sampler") {
+            std::string id, kind;
+            in >> id >> kind;
+            if (kind == "color") {
+                auto c = std::make_shared<rt::color_sampler>(next_vec3(in));
+                samplers[id] = c;
+                colors[id] = c;
+            } else {
+                std::string tex;
+                in >> tex;
+                samplers[id] = textures.at(tex);
+            }
+        } else if (tok == "background") {
+            std::string kind, id;
+            in >> kind >> id;
+            if (kind == "color") scene.background = colors.at(id);
+            else scene.background = std::make_shared<rt::equirectangular_map>(textures.at(id));
+        } else if (tok == "mesh") {
+            std::string id;
+            size_t count = 0;
+            in >> id >> count;
+            auto m = std::make_shared<rt::mesh>();
+            for (size_t t = 0; t < count; ++t) {
+                rt::triangle& tri = m->add_triangle();
+                for (rt::vertex& v : tri.vertices) {
+                    v.position = next_vec3(in);
+                    v.normal = next_vec3(in);
+                    v.uv.x = next_float(in);
+                    v.uv.y = next_float(in);
+                }
+            }
+            meshes[id] = m;
+        } else if (tok == "node") {
+            auto node = std::make_shared<rt::scene_node>();
+            std::string kind;
+            in >> kind;
+            if (kind == "sphere") node->shape = std::make_shared<rt::sphere>();
+            else {
+                std::string id;
+                in >> id;
+                node->shape = meshes.at(id);
+            }
+            for (int k = 0; k < 3; ++k) { // T, R, S in the loader's order (scene_loader.cpp:149-162)
+                std::string tag;
+                int present = 0;
+                in >> tag >> present;
+                if (!present) continue;
+                const glm::vec3 v = next_vec3(in);
+                if (tag == "T") node->translate(v);
+                else if (tag == "R")
+                    node->multiply(glm::rotate(glm::radians(v.z), glm::vec3(0.0f, 0.0f, 1.0f)) *
+                                   glm::rotate(glm::radians(v.y), glm::vec3(0.0f, 1.0f, 0.0f)) *
+                                   glm::rotate(glm::radians(v.x), glm::vec3(1.0f, 0.0f, 0.0f)));
+                else node->scale(v);
+            }
+            std::string tag, a, e, r, m;
+            in >> tag >> a >> e >> r >> m;
+            node->material.albedo = samplers.at(a);
+            node->material.emission = samplers.at(e);
+            node->material.roughness = samplers.at(r);
+            node->material.metallic = samplers.at(m);
+            scene.nodes.push_back(node);
+        } else {
+            return fail("unknown token '" + tok + "'");
+        }
+    }
+    return fail("missing 'end'");
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    uint32_t width = 512, height = 512;
+    uint64_t iterations = 10, spi = 256, seed = 0; // CLI/main.cpp:14-17,70
+    uint32_t threads = 4;
+    uint64_t interrupt_after = 0; // > 0: call interrupt() from the on_iteration_end handler (Sandbox-style stop)
+    int device = 0;
+    std::string scene_file, out_file = "result.bin", ldr_file;
+    for (int i = 1; i < argc; ++i) {
+        const std::string p = argv[i];
+        auto need = [&](int n) { return i + n < argc; };
+        if (p == "--scene" && need(1)) scene_file = argv[++i];
+        else if (p == "--out" && need(1)) out_file = argv[++i];
+        else if (p == "--ldr-out" && need(1)) ldr_file = argv[++i];
+        else if (p == "--threads" && need(1)) threads = uint32_t(std::stoul(argv[++i]));
+        else if (p == "--iterations" && need(1)) iterations = std::stoull(argv[++i]);
+        else if (p == "--spp-per-iteration" && need(1)) spi = std::stoull(argv[++i]);
+        else if (p == "--seed" && need(1)) seed = std::stoull(argv[++i]);
+        else if (p == "--device" && need(1)) device = std::stoi(argv[++i]);
+        else if (p == "--interrupt-after" && need(1)) interrupt_after = std::stoull(argv[++i]);
+        else if (p == "--resolution" && need(2)) {
+            width = uint32_t(std::stoul(argv[++i]));
+            height = uint32_t(std::stoul(argv[++i]));
+        } else {
+            std::fprintf(stderr, "Unknown parameter: %s\n", p.c_str());
+            return -1; // CLI/main.cpp:46-50
+        }
+    }
+
+    rt::scene scene;
+    if (!load_scene_text(scene_file, scene)) return 1;
+
+    rt::pathtracer pathtracer;
+    pathtracer.device.device = device;
+    pathtracer.device.seed = seed;
+    rt::view_parameters view_params;
+    rt::trace_parameters trace_params;
+    view_params.width = width;
+    view_params.height = height;
+    view_params.fov_y = glm::pi<float>() / 4.0f;
+    trace_params.num_threads = threads;
+    trace_params.iterations = iterations;
+    trace_params.samples_per_iteration = spi;
+
+    auto result = pathtracer.run(view_params, trace_params, scene);
+
+    uint64_t starts = 0, ends = 0;
+    result->on_iteration_start.subscribe([&starts](const uint64_t&) { ++starts; });
+    result->on_iteration_end.subscribe([&, result](const rt::image&, const uint64_t& iteration) {
+        ++ends;
+        const float elapsed = result->get_elapsed_time();
+        std::printf("iteration %" PRIu64 " / %" PRIu64 ", %.1f spp/sec\n", iteration + 1, iterations,
+                    result->samples_per_pixel.load() / elapsed);
+        if (interrupt_after && iteration + 1 >= interrupt_after) result->interrupt();
+    });
+    result->on_end.subscribe([&](const rt::image& image) {
+        std::ofstream out(out_file, std::ios::binary);
+        out.write(reinterpret_cast<const char*>(image.data()), std::streamsize(image.get_width() * image.get_height() * 12));
+        if (ldr_file.empty()) return;
+        // CLI/main.cpp:85-104: tone map, gamma, truncating 8-bit pack
+        std::vector<uint32_t> pixels(image.get_height() * image.get_width());
+        for (uint32_t x = 0; x < image.get_width(); ++x)
+            for (uint32_t y = 0; y < image.get_height(); ++y) {
+                glm::vec3 color = image.get_pixel(x, y);
+                color = glm::vec3(1.0f) - glm::exp(-color);
+                color = glm::pow(color, glm::vec3(1.0f / 2.2f));
+                pixels[y * image.get_width() + x] = (uint32_t(color.r * 255) << 0) | (uint32_t(color.g * 255) << 8) |
+                                                    (uint32_t(color.b * 255) << 16) | (uint32_t(255) << 24);
+            }
+        std::ofstream ldr(ldr_file, std::ios::binary);
+        ldr.write(reinterpret_cast<const char*>(pixels.data()), std::streamsize(pixels.size() * 4));
+    });
+    result->wait();
+
+    if (!result->error().empty()) {
+        std::fprintf(stderr, "rt_render: %s\n", result->error().c_str());
+        return 2;
+    }
+    std::printf("done: iteration=%" PRIu64 " spp=%" PRIu64 " paths=%" PRIu64 " rays=%" PRIu64 " events=%" PRIu64 "/%" PRIu64 "\n",
+                result->iteration.load(), result->samples_per_pixel.load(), result->paths_traced.load(),
+                result->rays_cast.load(), starts, ends);
+    return 0;
+}

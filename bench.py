@@ -22,10 +22,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SCENE = os.path.join(ROOT, "tests", "golden", "assets", "res", "scenes", "room.json")
+SCENES = os.path.join(ROOT, "tests", "golden", "assets", "res", "scenes")
+SCENE = os.path.join(SCENES, "room.json")
 W = H = 256
 SPI = 256
 FOV = math.pi / 4.0
+
+# BASELINE.json configs.  The headline metric is quoted on Room 256x256 (the default); the others are
+# reachable with --workload for the per-config numbers in DESIGN.md / profiles/.
+WORKLOADS = {
+    "room": dict(scene="room.json", w=256, h=256, desc="room.json 256x256, 10 nodes / 36 triangles / 2 spheres"),
+    "spheres": dict(scene="materials.json", w=512, h=512, desc="materials.json 512x512 (config 2), 25 spheres, equirect bg0.hdr"),
+    "mario": dict(scene="mario.json", w=128, h=128, desc="mario.json 128x128 (config 3), 14552-triangle KD mesh + 2048^2 texture"),
+    "synthetic": dict(scene=None, w=2048, h=2048, desc="synthetic displaced sphere (config 5), textured, equirect bg0.hdr"),
+}
+
+
+def load_workload(name, triangles):
+    from pathtracing_amd import load_scene, scene as S, workloads
+    wl = WORKLOADS[name]
+    if wl["scene"] is not None:
+        return load_scene(os.path.join(SCENES, wl["scene"]))
+    bg = S.load_image(os.path.join(ROOT, "tests", "golden", "assets", "res", "textures", "bg0.hdr"))
+    return workloads.synthetic_scene(triangles, 4096, bg)
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
 
@@ -76,7 +95,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal", type=int, default=None, help="PTK_OPT_TRAVERSAL override (0/1), for A/B runs")
+    ap.add_argument("--kd-prune", type=int, default=None, help="PTK_OPT_KD_PRUNE override (0/1), for A/B runs")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="room")
+    ap.add_argument("--triangles", type=int, default=5_000_000, help="synthetic workload: triangle count")
+    ap.add_argument("--resolution", type=int, nargs=2, default=None)
     args = ap.parse_args()
+    global W, H
+    W, H = args.resolution or (WORKLOADS[args.workload]["w"], WORKLOADS[args.workload]["h"])
 
     import torch
     import torch.distributed as dist
@@ -93,12 +118,14 @@ def main():
     if distributed:
         dist.init_process_group("nccl", device_id=dev)
 
-    scene = load_scene(SCENE)
+    scene = load_workload(args.workload, args.triangles)
     ctx = Context(local_rank)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     if args.traversal is not None:
         ctx.set_option(1, args.traversal)
+    if args.kd_prune is not None:
+        ctx.set_option(2, args.kd_prune)
     ctx.upload(scene)
     ctx.render_begin(W, H, FOV)
     total = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
@@ -151,14 +178,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"room.json {W}x{H}, {SPI} spp per GPU per step (one CLI iteration per GPU), "
-                                   "fov pi/4, depth 5, 10 nodes / 36 triangles / 2 spheres",
+            "config": {"workload": f"{WORKLOADS[args.workload]['desc']}; {W}x{H}, {SPI} spp per GPU per step "
+                                   "(one CLI iteration per GPU), fov pi/4, depth 5",
                        "paths_per_step_per_gpu": W * H * SPI, "rays_per_path": rays / paths,
                        "parallelism": f"sample-range x{world}" + (" + RCCL reduce(sum) to rank 0" if distributed else "")},
         }
         base = None
         flops_per_ray = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "room":
             base, flops_per_ray, _ = cpu_baseline(scene)
             out["cpu_baseline"] = base
         else:

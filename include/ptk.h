@@ -128,7 +128,13 @@ typedef struct ptk_kd_node {
     uint32_t skip;
     uint32_t first_prim; /* offset into the mesh's leaf-ordered prim list */
     uint32_t num_prims;  /* 0 for interior nodes (scene.cpp:280-284)      */
-    uint32_t depth;
+    uint32_t depth;      /* split axis of an interior node = depth % 3 (scene.cpp:230) */
+    /* Not in the reference: the box of the triangles stored below this node (whole
+     * triangles, slightly inflated).  bmin/bmax are the reference's cut boxes, which
+     * decide whether a leaf's triangles are tested at all; tmin/tmax only let the GPU
+     * skip subtrees that cannot hold a closer hit ("pruned traversal"). */
+    float tmin[3];
+    float tmax[3];
 } ptk_kd_node;
 
 typedef struct ptk_kd_info {
@@ -246,7 +252,12 @@ int ptk_reset_counters(ptk_ctx* ctx);
  * tested in the uniform loop and each lane then visits only the nodes whose box it pierced;
  * 2 (default) = 0 for the coherent primary rays of bounce 0, 1 for later bounces and for
  * ptk_intersect_batch.  No reference counterpart. */
-enum { PTK_OPT_TRAVERSAL = 1 };
+enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2 };
+/* PTK_OPT_KD_PRUNE: how a multi-node KD-tree is walked (mesh::intersect_internal,
+ * scene.cpp:188-212).  0 = the reference's order, every box-hit node is visited;
+ * 1 (default) = near child first (by the sign of the ray direction on the split axis),
+ * subtrees whose triangle box lies beyond the best hit so far are skipped, exact ties are
+ * resolved towards the reference's visiting order.  Same ids, same values. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's

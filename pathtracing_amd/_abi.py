@@ -84,6 +84,8 @@ class KdNode(C.Structure):
         ("first_prim", C.c_uint32),
         ("num_prims", C.c_uint32),
         ("depth", C.c_uint32),
+        ("tmin", C.c_float * 3),
+        ("tmax", C.c_float * 3),
     ]
 
 
@@ -107,6 +109,7 @@ class KernelTiming(C.Structure):
 
 
 PTK_OPT_TRAVERSAL = 1
+PTK_OPT_KD_PRUNE = 2
 PTK_KERNEL_NAMES = ["k_bounce<true>", "k_bounce<false>", "k_accumulate", "k_intersect_batch"]
 
 # name -> (restype, argtypes); every symbol include/ptk.h declares.

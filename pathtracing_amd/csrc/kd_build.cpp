@@ -9,6 +9,7 @@
 // by preorder positions: node i's left child is i+1, `skip` is the first node after
 // its subtree, which is all mesh::intersect_internal's recursion (scene.cpp:188-212)
 // needs.  Host-only code, no GPU calls.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -97,6 +98,48 @@ void build(Builder& b, std::vector<uint32_t>& idx, const float* bmin, const floa
     b.nodes[me].skip = static_cast<uint32_t>(b.nodes.size());
 }
 
+// Triangle boxes for the pruned traversal (not in the reference): a leaf's box covers its
+// whole triangles (which may stick out of the leaf's cut box), an interior node's box is
+// the union of its children's.  Children follow their parent in preorder, so one reverse
+// sweep fills every node.  Boxes are padded so that a hit position computed in fp32
+// (rounded, and accepted by `bar >= 0` with rounded barycentrics) is always inside.
+void fill_triangle_boxes(Builder& b)
+{
+    const float big = 3.402823466e+38f;
+    for (size_t i = b.nodes.size(); i-- > 0;) {
+        ptk_kd_node& n = b.nodes[i];
+        float lo[3] = { big, big, big }, hi[3] = { -big, -big, -big };
+        if (n.num_prims != 0 || i + 1 >= n.skip) {
+            for (uint32_t k = 0; k < n.num_prims; ++k) {
+                const ptk_triangle& t = b.tris[b.prims[n.first_prim + k]];
+                for (int v = 0; v < 3; ++v)
+                    for (int a = 0; a < 3; ++a) {
+                        const float p = t.v[v].position[a];
+                        if (p < lo[a]) lo[a] = p;
+                        if (p > hi[a]) hi[a] = p;
+                    }
+            }
+        } else {
+            for (size_t c = i + 1; c < n.skip; c = b.nodes[c].skip)
+                for (int a = 0; a < 3; ++a) {
+                    if (b.nodes[c].tmin[a] < lo[a]) lo[a] = b.nodes[c].tmin[a];
+                    if (b.nodes[c].tmax[a] > hi[a]) hi[a] = b.nodes[c].tmax[a];
+                }
+        }
+        std::memcpy(n.tmin, lo, 12);
+        std::memcpy(n.tmax, hi, 12);
+    }
+    for (ptk_kd_node& n : b.nodes)
+        for (int a = 0; a < 3; ++a) {
+            if (!(n.tmin[a] <= n.tmax[a])) continue; // empty leaf or NaN vertices: never pruned by this axis... kept as is
+            const float ext = n.tmax[a] - n.tmin[a];
+            const float mag = std::fmax(std::fabs(n.tmin[a]), std::fabs(n.tmax[a]));
+            const float pad = 1e-4f * ext + 1e-5f * mag + 1e-30f;
+            n.tmin[a] -= pad;
+            n.tmax[a] += pad;
+        }
+}
+
 } // namespace
 
 // Internal C++ entries used by ptk.hip as well.
@@ -109,6 +152,7 @@ void ptk_kd_build_vectors_bounded(const ptk_triangle* triangles, uint64_t num_tr
     std::vector<uint32_t> idx(num_triangles);
     for (uint64_t i = 0; i < num_triangles; ++i) idx[i] = static_cast<uint32_t>(i);
     build(b, idx, bmin, bmax, root_depth);
+    fill_triangle_boxes(b);
     if (info) {
         info->num_nodes = static_cast<uint32_t>(b.nodes.size());
         info->num_leaves = b.leaves;

@@ -329,6 +329,8 @@ struct ptk_ctx {
     unsigned long long* d_counters = nullptr;
 
     int traversal = 2; // PTK_OPT_TRAVERSAL
+    int kd_prune = 1;  // PTK_OPT_KD_PRUNE
+    bool deep_kd = false; // some mesh has more than one KD node (the pruned walk only pays off then)
 
     // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
     bool timing = false;
@@ -568,6 +570,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     std::vector<float4> tri_hit, tri_shade;
     std::vector<uint32_t> leaf_prim;
     c->kd_infos.resize(sc->num_meshes);
+    bool deep_kd = false;
     for (uint32_t m = 0; m < sc->num_meshes; ++m) {
         const ptk_mesh_desc& md = sc->meshes[m];
         std::vector<ptk_kd_node> nodes;
@@ -580,16 +583,26 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         dm.kd_count = (uint32_t)nodes.size();
         dm.leaf_base = (uint32_t)leaf_prim.size();
         dm.shade_base = (uint32_t)(tri_shade.size() / 4);
-        for (const ptk_kd_node& n : nodes) {
+        if (c->kd_infos[m].max_depth > PTK_KD_MAX_DEPTH)
+            return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: KD-tree deeper than PTK_KD_MAX_DEPTH");
+        if (nodes.size() > 1) deep_kd = true;
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            const ptk_kd_node& n = nodes[i];
             DKdNode k;
             std::memcpy(k.bmin, n.bmin, 12);
             std::memcpy(k.bmax, n.bmax, 12);
+            std::memcpy(k.tmin, n.tmin, 12);
+            std::memcpy(k.tmax, n.tmax, 12);
+            k.axis = n.depth % 3u; // scene.cpp:230
             if (n.num_prims) {
                 k.a = n.first_prim;
                 k.b = n.num_prims;
+                k.right = n.skip;
             } else {
                 k.a = n.skip;
                 k.b = 0;
+                // left child = next preorder slot; right child starts where the left subtree ends
+                k.right = (i + 1 < nodes.size() && i + 1 < n.skip) ? nodes[i + 1].skip : n.skip;
             }
             kd.push_back(k);
         }
@@ -660,6 +673,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     c->num_samplers = sc->num_samplers;
     c->num_textures = sc->num_textures;
     c->has_scene = true;
+    c->deep_kd = deep_kd;
     // camera direction feeds the view basis built by ptk_render_begin
     std::memcpy(c->cam_dir, sc->camera.direction, sizeof(c->cam_dir));
     c->has_view = false;
@@ -699,10 +713,14 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
     const uint32_t blocks = (uint32_t)((n + kBlock - 1) / kBlock);
     {
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
-        if (c->traversal >= 1)
-            k_intersect_batch<1><<<dim3(blocks), dim3(kBlock), 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv);
-        else
-            k_intersect_batch<0><<<dim3(blocks), dim3(kBlock), 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv);
+        const int mode = (c->traversal >= 1 ? 1 : 0) | ((c->kd_prune && c->deep_kd) ? 2 : 0);
+        const dim3 g(blocks), b(kBlock);
+        switch (mode) {
+        case 0: k_intersect_batch<0><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv); break;
+        case 1: k_intersect_batch<1><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv); break;
+        case 2: k_intersect_batch<2><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv); break;
+        default: k_intersect_batch<3><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv); break;
+        }
     }
     PTK_HIP(c, hipGetLastError());
     return PTK_OK;
@@ -829,16 +847,26 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
             A.sample_begin = sample_begin + s0;
             A.seed = seed;
             A.bounce = 0;
+            const int prune_bit = (c->kd_prune && c->deep_kd) ? 2 : 0;
+            const dim3 grid(A.num_segments), block(kBlock);
             {
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
-                if (c->traversal == 1) k_bounce<true, 1><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
-                else k_bounce<true, 0><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+                switch ((c->traversal == 1 ? 1 : 0) | prune_bit) {
+                case 0: k_bounce<true, 0><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                case 1: k_bounce<true, 1><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                case 2: k_bounce<true, 2><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                default: k_bounce<true, 3><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                }
             }
             for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) {
                 A.bounce = b;
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_NEXT);
-                if (c->traversal >= 1) k_bounce<false, 1><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
-                else k_bounce<false, 0><<<dim3(A.num_segments), dim3(kBlock), 0, c->stream>>>(c->S, c->V, A);
+                switch ((c->traversal >= 1 ? 1 : 0) | prune_bit) {
+                case 0: k_bounce<false, 0><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                case 1: k_bounce<false, 1><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                case 2: k_bounce<false, 2><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                default: k_bounce<false, 3><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                }
             }
             const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
             {
@@ -927,6 +955,10 @@ int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
     if (!c) return PTK_ERR_INVALID;
     if (option == PTK_OPT_TRAVERSAL && value >= 0 && value <= 2) {
         c->traversal = value;
+        return PTK_OK;
+    }
+    if (option == PTK_OPT_KD_PRUNE && (value == 0 || value == 1)) {
+        c->kd_prune = value;
         return PTK_OK;
     }
     return fail(c, PTK_ERR_INVALID, "ptk_ctx_set_option: unknown option or value");

@@ -28,16 +28,24 @@ struct alignas(16) DNode {
 };
 static_assert(sizeof(DNode) == 256, "DNode must be 256 B");
 
-// Flattened KD node, 32 B = two dwordx4 loads.
+// Flattened KD node, 64 B = four dwordx4 loads (the reference-order walk reads only the
+// first two).
 //   interior: a = skip index (first node after the subtree), b = 0
 //   leaf:     a = first leaf-ordered primitive,            b = primitive count
+// bmin/bmax: the reference's cut box (scene.cpp:251), which decides whether the node is
+// entered.  tmin/tmax: padded box of the triangles below the node (ptk_kd_node::tmin),
+// axis = split axis, right = index of the right child; used by the pruned walk only.
 struct alignas(16) DKdNode {
     float bmin[3];
     uint32_t a;
     float bmax[3];
     uint32_t b;
+    float tmin[3];
+    uint32_t axis;
+    float tmax[3];
+    uint32_t right;
 };
-static_assert(sizeof(DKdNode) == 32, "DKdNode must be 32 B");
+static_assert(sizeof(DKdNode) == 64, "DKdNode must be 64 B");
 
 // Per-mesh header.
 struct alignas(16) DMesh {
@@ -150,9 +158,13 @@ struct Hit {
 
 // scene.cpp:142-186 mesh::intersect_triangle up to the hit decision, plus the
 // distance bookkeeping of intersect_internal (scene.cpp:196-202).  Returns true
-// and updates (best_d, bar, p) when this triangle is hit and strictly closer.
+// and updates (best_d, best_slot, bar, p) when this triangle is hit and strictly closer,
+// or exactly as close but earlier in the reference's visiting order (`slot` = position in
+// the leaf-ordered primitive list = DFS order).  Walked in the reference's own order the
+// slot only ever grows, so the second clause never fires and this is the strict `<` of
+// scene.cpp:198; it is what makes any other visiting order return the same triangle.
 __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o,
-                                         V3 d, float& best_d, V3& bar_out, V3& p_out)
+                                         V3 d, int slot, float& best_d, int& best_slot, V3& bar_out, V3& p_out)
 {
     const V3 v0 = mk(q0.x, q0.y, q0.z);
     const V3 N = mk(q0.w, q1.x, q1.y);
@@ -174,8 +186,9 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
     if (u >= 0 && v >= 0 && w >= 0) {
         const V3 dv = o - projection;
         const float dd = dot(dv, dv);
-        if (dd < best_d) {
+        if (dd < best_d || (dd == best_d && slot < best_slot)) {
             best_d = dd;
+            best_slot = slot;
             bar_out = mk(u, v, w);
             p_out = projection;
             return true;
@@ -184,59 +197,164 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
     return false;
 }
 
-// mesh::intersect + intersect_internal, scene.cpp:115-121,188-212, on the
-// flattened preorder tree.  The reference's recursion "box hit -> own triangles,
-// then left subtree, then right subtree" is the loop "box hit or leaf -> i+1,
-// interior box miss -> skip"; visiting order and the strict `<` are unchanged, so
-// exact ties resolve to the same primitive.  No stack is needed because the
-// reference never orders or prunes children.
-__device__ __forceinline__ bool mesh_intersect(const DScene& S, const DMesh mesh, V3 o, V3 d, bool lane_on,
-                                               int& prim_out, V3& bar_out, V3& p_out)
+// One leaf's triangles, per-lane addresses (scene.cpp:192-203).
+__device__ __forceinline__ void leaf_triangles(const DScene& S, uint32_t first, uint32_t count, V3 o, V3 d,
+                                               float& best_d, int& best_slot, bool& found, V3& bar_out, V3& p_out)
 {
-    float best_d = 3.402823466e+38f;
-    bool found = false;
-    if (mesh.kd_count == 1u) {
-        // Single-leaf mesh (plane.obj, cube.obj: the 1.5x rule keeps them whole).
-        // Every lane walks the same triangles, so the records come in through
-        // wave-uniform (scalar) loads and only the box test is per lane.
-        const DKdNode kn = S.kd[mesh.kd_base];
-        const bool inside = lane_on && box_intersect(kn.bmin[0], kn.bmin[1], kn.bmin[2], kn.bmax[0], kn.bmax[1],
-                                                     kn.bmax[2], o, d);
-        if (__builtin_amdgcn_ballot_w64(inside) != 0ull) {
-            const uint32_t first = mesh.leaf_base + kn.a;
-            for (uint32_t k = 0; k < kn.b; ++k) {
-                const float4* t = S.tri_hit + (size_t)(first + k) * 4;
-                const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
-                if (inside && tri_test(q0, q1, q2, q3, o, d, best_d, bar_out, p_out)) {
-                    prim_out = (int)(first + k);
-                    found = true;
-                }
-            }
-        }
-        return found;
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4* t = S.tri_hit + (size_t)(first + k) * 4;
+        const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
+        if (tri_test(q0, q1, q2, q3, o, d, (int)(first + k), best_d, best_slot, bar_out, p_out)) found = true;
     }
+}
+
+// ---- KD walk, reference order -------------------------------------------------
+// mesh::intersect + intersect_internal, scene.cpp:115-121,188-212, on the flattened
+// preorder tree.  The reference's recursion "box hit -> own triangles, then left
+// subtree, then right subtree" is the loop "box hit or leaf -> i+1, interior box miss ->
+// skip"; visiting order and the strict `<` are unchanged.  No stack is needed because
+// the reference never orders or prunes children.  `start` = 1 when the caller has
+// already tested (and entered) the root.
+__device__ __forceinline__ void kd_walk_reference(const DScene& S, const DMesh mesh, V3 o, V3 d, uint32_t start,
+                                                  float& best_d, int& best_slot, bool& found, V3& bar_out, V3& p_out)
+{
     const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
-    uint32_t i = lane_on ? 0u : mesh.kd_count;
+    uint32_t i = start;
     while (i < mesh.kd_count) {
         const float4 n0 = reinterpret_cast<const float4*>(kd + i)[0];
         const float4 n1 = reinterpret_cast<const float4*>(kd + i)[1];
         const uint32_t a = __float_as_uint(n0.w);
         const uint32_t b = __float_as_uint(n1.w);
         const bool hit = box_intersect(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, o, d);
-        if (hit && b != 0u) {
-            const uint32_t first = mesh.leaf_base + a;
-            for (uint32_t k = 0; k < b; ++k) {
-                const float4* t = S.tri_hit + (size_t)(first + k) * 4;
-                const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
-                if (tri_test(q0, q1, q2, q3, o, d, best_d, bar_out, p_out)) {
-                    prim_out = (int)(first + k);
-                    found = true;
-                }
-            }
-        }
+        if (hit && b != 0u) leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, best_slot, found, bar_out, p_out);
         i = (hit || b != 0u) ? i + 1u : a;
     }
+}
+
+// ---- KD walk, pruned ----------------------------------------------------------
+// Same result as kd_walk_reference, far fewer nodes.  What the reference returns is
+// fully described by: among all (leaf slot, triangle) pairs whose leaf is reached through
+// cut boxes that all pass bounding_box::intersect, the pair with the smallest squared
+// distance, the lowest slot on exact ties.  So
+//   * a node is entered only if the reference's own box test passes (same arithmetic);
+//   * children are visited near-first: the two cut boxes of a node are separated by the
+//     split plane, so the sign of the ray direction on the split axis gives front-to-back;
+//   * a subtree is skipped when its padded triangle box (DKdNode::tmin/tmax) is missed, is
+//     behind the origin, or starts farther than the best hit so far.  Every hit position
+//     lies inside that box, so a skipped subtree holds no hit at all or only hits that are
+//     strictly farther than the current best (margins below cover fp32 rounding of both the
+//     slab arithmetic and the hit distance), hence neither a winner nor a tie;
+//   * exact ties between visited candidates go to the lower slot (tri_test).
+// The stack holds one pending far child per level: depth <= PTK_KD_MAX_DEPTH.
+constexpr int kKdStack = (int)PTK_KD_MAX_DEPTH + 4;
+
+__device__ __forceinline__ bool kd_prune(const float4 t0, const float4 t1, V3 o, V3 inv, float oabs, float best_d)
+{
+    const float ax = (t0.x - o.x) * inv.x, bx = (t1.x - o.x) * inv.x;
+    const float ay = (t0.y - o.y) * inv.y, by = (t1.y - o.y) * inv.y;
+    const float az = (t0.z - o.z) * inv.z, bz = (t1.z - o.z) * inv.z;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    // every comparison is false on NaN, i.e. "do not prune"
+    const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)) + 2.0f * oabs;
+    const bool behind = t_out < 0.0f && t_out * 0.99999f < -oabs;
+    const float near_lo = t_in * 0.99999f - oabs;
+    const bool beyond = near_lo > 0.0f && near_lo * near_lo > best_d;
+    return missed || behind || beyond;
+}
+
+__device__ __forceinline__ void kd_walk_pruned(const DScene& S, const DMesh mesh, V3 o, V3 d, bool work,
+                                               float& best_d, int& best_slot, bool& found, V3& bar_out, V3& p_out)
+{
+    const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
+    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const float oabs = 1e-5f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + 1e-30f;
+    const uint32_t neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    uint32_t stack[kKdStack];
+    int sp = 0;
+    const uint32_t none = 0xFFFFFFFFu;
+    uint32_t cur = work ? 0u : none;
+    while (cur != none) {
+        const float4* __restrict__ q = reinterpret_cast<const float4*>(kd + cur);
+        const float4 c0 = q[0], c1 = q[1], t0 = q[2], t1 = q[3];
+        const uint32_t a = __float_as_uint(c0.w);
+        const uint32_t b = __float_as_uint(c1.w);
+        const bool enter = box_intersect(c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, o, d) &&
+                           !kd_prune(t0, t1, o, inv, oabs, best_d);
+        uint32_t next = none;
+        if (enter) {
+            if (b != 0u) {
+                leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, best_slot, found, bar_out, p_out);
+            } else {
+                const uint32_t right = __float_as_uint(t1.w);
+                const bool has_right = right < a; // a = end of this subtree
+                const bool right_first = has_right && ((neg >> __float_as_uint(t0.w)) & 1u) != 0u;
+                next = right_first ? right : cur + 1u;
+                if (has_right && sp < kKdStack) stack[sp++] = right_first ? cur + 1u : right;
+            }
+        }
+        if (next == none && sp > 0) next = stack[--sp];
+        cur = next;
+    }
+}
+
+// mesh::intersect (scene.cpp:115-121) for one lane.  `entered_root`: the caller has
+// already run the reference's box test on the root and it passed.
+template <bool PRUNE>
+__device__ __forceinline__ bool mesh_traverse_lane(const DScene& S, const DMesh mesh, V3 o, V3 d, bool work,
+                                                   bool entered_root, int& prim_out, V3& bar_out, V3& p_out)
+{
+    float best_d = 3.402823466e+38f;
+    int best_slot = 0x7FFFFFFF;
+    bool found = false;
+    const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
+    if (PRUNE) {
+        // a one-leaf mesh whose root the caller already entered needs no walk at all
+        const bool flat = work && entered_root && mesh.kd_count == 1u;
+        if (flat) leaf_triangles(S, mesh.leaf_base + kd->a, kd->b, o, d, best_d, best_slot, found, bar_out, p_out);
+        kd_walk_pruned(S, mesh, o, d, work && !flat, best_d, best_slot, found, bar_out, p_out);
+    } else {
+        uint32_t start = work ? 0u : mesh.kd_count;
+        if (work && entered_root) {
+            const uint32_t a = kd->a, b = kd->b;
+            if (b != 0u) leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, best_slot, found, bar_out, p_out);
+            start = 1u; // a leaf root has kd_count == 1
+        }
+        kd_walk_reference(S, mesh, o, d, start, best_d, best_slot, found, bar_out, p_out);
+    }
+    prim_out = found ? best_slot : prim_out;
     return found;
+}
+
+// mesh::intersect for a whole wave walking the same mesh node (traversal mode 0).
+template <bool PRUNE>
+__device__ __forceinline__ bool mesh_intersect(const DScene& S, const DMesh mesh, V3 o, V3 d, bool lane_on,
+                                               int& prim_out, V3& bar_out, V3& p_out)
+{
+    if (mesh.kd_count == 1u) {
+        // Single-leaf mesh (plane.obj, cube.obj: the 1.5x rule keeps them whole).
+        // Every lane walks the same triangles, so the records come in through
+        // wave-uniform (scalar) loads and only the box test is per lane.
+        float best_d = 3.402823466e+38f;
+        int best_slot = 0x7FFFFFFF;
+        bool found = false;
+        const DKdNode* __restrict__ kn = S.kd + mesh.kd_base;
+        const bool inside = lane_on && box_intersect(kn->bmin[0], kn->bmin[1], kn->bmin[2], kn->bmax[0], kn->bmax[1],
+                                                     kn->bmax[2], o, d);
+        if (__builtin_amdgcn_ballot_w64(inside) != 0ull) {
+            const uint32_t first = mesh.leaf_base + kn->a;
+            const uint32_t count = kn->b;
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4* t = S.tri_hit + (size_t)(first + k) * 4;
+                const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
+                if (inside && tri_test(q0, q1, q2, q3, o, d, (int)(first + k), best_d, best_slot, bar_out, p_out))
+                    found = true;
+            }
+        }
+        prim_out = found ? best_slot : prim_out;
+        return found;
+    }
+    return mesh_traverse_lane<PRUNE>(S, mesh, o, d, lane_on, false, prim_out, bar_out, p_out);
 }
 
 // sphere::intersect up to the hit position, scene.cpp:401-432.
@@ -256,6 +374,7 @@ __device__ __forceinline__ bool sphere_intersect(V3 o, V3 d, V3& p_out)
 // scene::cast_ray, scene.cpp:355-399.  All lanes of a wave walk the node table
 // together (there is no top-level structure in the reference: every ray tests
 // every node), so the node record and the sphere/mesh branch are wave-uniform.
+template <bool PRUNE>
 __device__ __forceinline__ void intersect_scene(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
 {
     best.d0 = 3.402823466e+38f;
@@ -275,7 +394,7 @@ __device__ __forceinline__ void intersect_scene(const DScene& S, V3 o, V3 d, boo
             hit = lane_on && sphere_intersect(lo, ld, p);
             a = p;
         } else {
-            hit = mesh_intersect(S, S.meshes[nd->mesh], lo, ld, lane_on, prim, a, p);
+            hit = mesh_intersect<PRUNE>(S, S.meshes[nd->mesh], lo, ld, lane_on, prim, a, p);
         }
         if (hit) {
             const V3 pw = mat_point(nd->xf, p, 1.0f); // scene.cpp:375
@@ -319,47 +438,7 @@ __device__ __forceinline__ void best_update(Hit& best, float d0, int n, int prim
     }
 }
 
-// One leaf's triangles, per-lane addresses (scene.cpp:192-203).
-__device__ __forceinline__ void leaf_triangles(const DScene& S, uint32_t first, uint32_t count, V3 o, V3 d,
-                                               float& best_d, bool& found, int& prim_out, V3& bar_out, V3& p_out)
-{
-    for (uint32_t k = 0; k < count; ++k) {
-        const float4* t = S.tri_hit + (size_t)(first + k) * 4;
-        const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
-        if (tri_test(q0, q1, q2, q3, o, d, best_d, bar_out, p_out)) {
-            prim_out = (int)(first + k);
-            found = true;
-        }
-    }
-}
-
-// mesh::intersect for a lane whose root-box test already passed (scene.cpp:190).
-__device__ __forceinline__ bool mesh_traverse_lane(const DScene& S, const DMesh mesh, V3 o, V3 d, bool work,
-                                                   int& prim_out, V3& bar_out, V3& p_out)
-{
-    float best_d = 3.402823466e+38f;
-    bool found = false;
-    const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
-    uint32_t i = mesh.kd_count;
-    if (work) {
-        const float4 r0 = reinterpret_cast<const float4*>(kd)[0];
-        const float4 r1 = reinterpret_cast<const float4*>(kd)[1];
-        const uint32_t a = __float_as_uint(r0.w), b = __float_as_uint(r1.w);
-        if (b != 0u) leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, found, prim_out, bar_out, p_out);
-        i = 1u; // root hit: continue with its first child (a leaf root has kd_count == 1)
-    }
-    while (i < mesh.kd_count) {
-        const float4 n0 = reinterpret_cast<const float4*>(kd + i)[0];
-        const float4 n1 = reinterpret_cast<const float4*>(kd + i)[1];
-        const uint32_t a = __float_as_uint(n0.w);
-        const uint32_t b = __float_as_uint(n1.w);
-        const bool hit = box_intersect(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, o, d);
-        if (hit && b != 0u) leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, found, prim_out, bar_out, p_out);
-        i = (hit || b != 0u) ? i + 1u : a;
-    }
-    return found;
-}
-
+template <bool PRUNE>
 __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
 {
     best.d0 = 3.402823466e+38f;
@@ -407,7 +486,7 @@ __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, 
             const DMesh mesh = S.meshes[mesh_idx];
             int prim = -1;
             V3 p = mk(0.0f, 0.0f, 0.0f), a = mk(0.0f, 0.0f, 0.0f);
-            if (mesh_traverse_lane(S, mesh, lo, ld, work, prim, a, p)) {
+            if (mesh_traverse_lane<PRUNE>(S, mesh, lo, ld, work, true, prim, a, p)) {
                 const float4 x0 = nv[4], x1 = nv[5], x2 = nv[6], x3 = nv[7];
                 const V3 pw = mk((x0.x * p.x + x1.x * p.y) + (x2.x * p.z + x3.x * 1.0f),
                                  (x0.y * p.x + x1.y * p.y) + (x2.y * p.z + x3.y * 1.0f),
@@ -419,11 +498,12 @@ __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, 
     }
 }
 
+// MODE bit 0: node-loop mapping (PTK_OPT_TRAVERSAL), bit 1: pruned KD walk (PTK_OPT_KD_PRUNE).
 template <int MODE>
 __device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
 {
-    if (MODE == 1) intersect_scene_lanelist(S, o, d, lane_on, best);
-    else intersect_scene(S, o, d, lane_on, best);
+    if (MODE & 1) intersect_scene_lanelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
+    else intersect_scene<(MODE & 2) != 0>(S, o, d, lane_on, best);
 }
 
 // Rebuilds raycast_result::normal / uv for the winning hit only (the reference

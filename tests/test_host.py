@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
 def test_abi_struct_sizes_match_header():
     assert C.sizeof(_abi.Vertex) == 32 and C.sizeof(_abi.Triangle) == 96
     assert C.sizeof(_abi.NodeDesc) == 3 * 64 + 6 * 4
-    assert C.sizeof(_abi.KdNode) == 40
+    assert C.sizeof(_abi.KdNode) == 64
     assert C.sizeof(_abi.SamplerDesc) == 24 and C.sizeof(_abi.BackgroundDesc) == 24
     assert C.sizeof(_abi.CameraDesc) == 24
 

@@ -589,20 +589,25 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         for (size_t i = 0; i < nodes.size(); ++i) {
             const ptk_kd_node& n = nodes[i];
             DKdNode k;
-            std::memcpy(k.bmin, n.bmin, 12);
-            std::memcpy(k.bmax, n.bmax, 12);
+            std::memcpy(k.cmin, n.bmin, 12);
+            std::memcpy(k.cmax, n.bmax, 12);
             std::memcpy(k.tmin, n.tmin, 12);
             std::memcpy(k.tmax, n.tmax, 12);
-            k.axis = n.depth % 3u; // scene.cpp:230
+            const uint32_t axis = n.depth % 3u; // scene.cpp:230
+            k.split = 0.0f;
             if (n.num_prims) {
+                if (n.num_prims > kKdCountMask) return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: leaf too large");
                 k.a = n.first_prim;
-                k.b = n.num_prims;
+                k.b_axis = n.num_prims | (axis << 30);
                 k.right = n.skip;
             } else {
                 k.a = n.skip;
-                k.b = 0;
-                // left child = next preorder slot; right child starts where the left subtree ends
-                k.right = (i + 1 < nodes.size() && i + 1 < n.skip) ? nodes[i + 1].skip : n.skip;
+                k.b_axis = axis << 30;
+                // left child = next preorder slot (its box is this box cut at `split` from above,
+                // scene.cpp:31-56); the right child starts where the left subtree ends
+                const bool has_left = i + 1 < nodes.size() && i + 1 < n.skip;
+                k.right = has_left ? nodes[i + 1].skip : n.skip;
+                if (has_left) k.split = nodes[i + 1].bmax[axis];
             }
             kd.push_back(k);
         }

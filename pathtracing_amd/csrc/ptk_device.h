@@ -28,24 +28,26 @@ struct alignas(16) DNode {
 };
 static_assert(sizeof(DNode) == 256, "DNode must be 256 B");
 
-// Flattened KD node, 64 B = four dwordx4 loads (the reference-order walk reads only the
-// first two).
-//   interior: a = skip index (first node after the subtree), b = 0
-//   leaf:     a = first leaf-ordered primitive,            b = primitive count
-// bmin/bmax: the reference's cut box (scene.cpp:251), which decides whether the node is
-// entered.  tmin/tmax: padded box of the triangles below the node (ptk_kd_node::tmin),
-// axis = split axis, right = index of the right child; used by the pruned walk only.
+// Flattened KD node, 64 B = four 16-B words:
+//   h = { a, b | axis<<30, right, split }   header
+//        interior: a = skip index (first node after the subtree), b = 0, right = index of
+//                  the right child (the left child is the next slot), split = the plane the
+//                  node's box is cut at (scene.cpp:240-251), axis = depth % 3
+//        leaf:     a = first leaf-ordered primitive, b = primitive count (> 0)
+//   x = { cmin.x, cmin.y, cmin.z, cmax.x }   c* = the reference's cut box (scene.cpp:251):
+//   y = { cmax.y, cmax.z, tmin.x, tmin.y }        decides whether the node is entered
+//   z = { tmin.z, tmax.x, tmax.y, tmax.z }   t* = padded box of the triangles below the node
+//                                                 (ptk_kd_node::tmin/tmax): pruning only
 struct alignas(16) DKdNode {
-    float bmin[3];
-    uint32_t a;
-    float bmax[3];
-    uint32_t b;
+    uint32_t a, b_axis, right;
+    float split;
+    float cmin[3];
+    float cmax[3];
     float tmin[3];
-    uint32_t axis;
     float tmax[3];
-    uint32_t right;
 };
 static_assert(sizeof(DKdNode) == 64, "DKdNode must be 64 B");
+constexpr uint32_t kKdCountMask = 0x3FFFFFFFu;
 
 // Per-mesh header.
 struct alignas(16) DMesh {
@@ -129,7 +131,19 @@ __device__ __forceinline__ V3 mat_point(const float* __restrict__ m, V3 p, float
 // ---------------------------------------------------------------- intersectors
 
 // scene.cpp:58-75  bounding_box::intersect (quirks kept: six divides, NaN-ignoring
-// fmin/fmax, and the `t9 != -1` test that rejects an entry distance of exactly -1).
+// fmin/fmax, and the `t9 != -1` test that rejects an entry distance of exactly -1), in two
+// steps: the six plane quotients, then the decision.  A KD child's box is its parent's box
+// with one plane moved to the split (scene.cpp:31-56), so a walk that keeps the parent's
+// six quotients only has to divide once per node to get both children's; the values are the
+// ones the reference computes (same operands, same IEEE divide).
+__device__ __forceinline__ bool slab_decide(float t1, float t2, float t3, float t4, float t5, float t6)
+{
+    const float t7 = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    const float t8 = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    const float t9 = (t8 < 0 || t7 > t8) ? -1.0f : t7;
+    return t9 != -1.0f;
+}
+
 __device__ __forceinline__ bool box_intersect(float minx, float miny, float minz, float maxx, float maxy,
                                               float maxz, V3 o, V3 d)
 {
@@ -139,10 +153,7 @@ __device__ __forceinline__ bool box_intersect(float minx, float miny, float minz
     const float t4 = (maxy - o.y) / d.y;
     const float t5 = (minz - o.z) / d.z;
     const float t6 = (maxz - o.z) / d.z;
-    const float t7 = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-    const float t8 = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-    const float t9 = (t8 < 0 || t7 > t8) ? -1.0f : t7;
-    return t9 != -1.0f;
+    return slab_decide(t1, t2, t3, t4, t5, t6);
 }
 
 // Closest-hit record carried through the node loop.  For a triangle a* holds the
@@ -221,11 +232,11 @@ __device__ __forceinline__ void kd_walk_reference(const DScene& S, const DMesh m
     const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
     uint32_t i = start;
     while (i < mesh.kd_count) {
-        const float4 n0 = reinterpret_cast<const float4*>(kd + i)[0];
-        const float4 n1 = reinterpret_cast<const float4*>(kd + i)[1];
-        const uint32_t a = __float_as_uint(n0.w);
-        const uint32_t b = __float_as_uint(n1.w);
-        const bool hit = box_intersect(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, o, d);
+        const float4* __restrict__ q = reinterpret_cast<const float4*>(kd + i);
+        const float4 h = q[0], x = q[1], y = q[2];
+        const uint32_t a = __float_as_uint(h.x);
+        const uint32_t b = __float_as_uint(h.y) & kKdCountMask;
+        const bool hit = box_intersect(x.x, x.y, x.z, x.w, y.x, y.y, o, d);
         if (hit && b != 0u) leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, best_slot, found, bar_out, p_out);
         i = (hit || b != 0u) ? i + 1u : a;
     }
@@ -248,21 +259,33 @@ __device__ __forceinline__ void kd_walk_reference(const DScene& S, const DMesh m
 // The stack holds one pending far child per level: depth <= PTK_KD_MAX_DEPTH.
 constexpr int kKdStack = (int)PTK_KD_MAX_DEPTH + 4;
 
-__device__ __forceinline__ bool kd_prune(const float4 t0, const float4 t1, V3 o, V3 inv, float oabs, float best_d)
+// Returns true when the subtree under a node can be skipped; `bound` receives a lower bound
+// of the squared distance of any hit below it (0 when the origin may be inside the box).
+// y = {.., .., tmin.x, tmin.y}, z = {tmin.z, tmax.x, tmax.y, tmax.z} of the node record.
+__device__ __forceinline__ bool kd_prune(const float4 y, const float4 z, V3 o, V3 inv, float oabs, float best_d,
+                                         float& bound)
 {
-    const float ax = (t0.x - o.x) * inv.x, bx = (t1.x - o.x) * inv.x;
-    const float ay = (t0.y - o.y) * inv.y, by = (t1.y - o.y) * inv.y;
-    const float az = (t0.z - o.z) * inv.z, bz = (t1.z - o.z) * inv.z;
+    const float ax = (y.z - o.x) * inv.x, bx = (z.y - o.x) * inv.x;
+    const float ay = (y.w - o.y) * inv.y, by = (z.z - o.y) * inv.y;
+    const float az = (z.x - o.z) * inv.z, bz = (z.w - o.z) * inv.z;
     const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     // every comparison is false on NaN, i.e. "do not prune"
     const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)) + 2.0f * oabs;
     const bool behind = t_out < 0.0f && t_out * 0.99999f < -oabs;
     const float near_lo = t_in * 0.99999f - oabs;
-    const bool beyond = near_lo > 0.0f && near_lo * near_lo > best_d;
-    return missed || behind || beyond;
+    bound = near_lo > 0.0f ? near_lo * near_lo : 0.0f;
+    return missed || behind || bound > best_d;
 }
 
+// Loop shape ("while-while"): all lanes of a wave first descend through interior nodes,
+// testing BOTH children of the current node per step (their loads are issued together, and
+// a child that fails never touches the stack), then all lanes that reached a leaf test its
+// triangles.  The six plane quotients of the current node's cut box are carried in
+// registers: one IEEE divide per step yields both children's reference box tests
+// (slab_decide).  A pending far child is pushed with its distance bound, so a pop can
+// discard it against the best hit found meanwhile without touching memory; a node that
+// is popped gets its six quotients recomputed from its own box.
 __device__ __forceinline__ void kd_walk_pruned(const DScene& S, const DMesh mesh, V3 o, V3 d, bool work,
                                                float& best_d, int& best_slot, bool& found, V3& bar_out, V3& p_out)
 {
@@ -270,31 +293,91 @@ __device__ __forceinline__ void kd_walk_pruned(const DScene& S, const DMesh mesh
     const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const float oabs = 1e-5f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + 1e-30f;
     const uint32_t neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    uint32_t stack[kKdStack];
-    int sp = 0;
     const uint32_t none = 0xFFFFFFFFu;
-    uint32_t cur = work ? 0u : none;
+    uint32_t stack_i[kKdStack];
+    float stack_t[kKdStack];
+    int sp = 0;
+    // header of the node being processed (it has passed both tests) and its six quotients
+    uint32_t cur = none, ca = 0u, cb = 0u, cr = 0u;
+    float cs = 0.0f;
+    float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f, T4 = 0.0f, T5 = 0.0f, T6 = 0.0f;
+
+    // (re)starts at node `idx`: header words + quotients from its own cut box
+    auto enter = [&](uint32_t idx) {
+        const float4* __restrict__ q = reinterpret_cast<const float4*>(kd + idx);
+        const float4 h = q[0], x = q[1], y = q[2];
+        cur = idx;
+        ca = __float_as_uint(h.x);
+        cb = __float_as_uint(h.y);
+        cr = __float_as_uint(h.z);
+        cs = h.w;
+        T1 = (x.x - o.x) / d.x;
+        T2 = (x.w - o.x) / d.x;
+        T3 = (x.y - o.y) / d.y;
+        T4 = (y.x - o.y) / d.y;
+        T5 = (x.z - o.z) / d.z;
+        T6 = (y.y - o.z) / d.z;
+    };
+    auto pop = [&]() {
+        cur = none;
+        while (sp > 0) {
+            --sp;
+            if (stack_t[sp] > best_d) continue;
+            enter(stack_i[sp]);
+            break;
+        }
+    };
+
+    if (work) {
+        enter(0u);
+        const float4* __restrict__ q = reinterpret_cast<const float4*>(kd);
+        float bound;
+        if (!slab_decide(T1, T2, T3, T4, T5, T6) || kd_prune(q[2], q[3], o, inv, oabs, best_d, bound)) cur = none;
+    }
     while (cur != none) {
-        const float4* __restrict__ q = reinterpret_cast<const float4*>(kd + cur);
-        const float4 c0 = q[0], c1 = q[1], t0 = q[2], t1 = q[3];
-        const uint32_t a = __float_as_uint(c0.w);
-        const uint32_t b = __float_as_uint(c1.w);
-        const bool enter = box_intersect(c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, o, d) &&
-                           !kd_prune(t0, t1, o, inv, oabs, best_d);
-        uint32_t next = none;
-        if (enter) {
-            if (b != 0u) {
-                leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, best_slot, found, bar_out, p_out);
+        while (cur != none && (cb & kKdCountMask) == 0u) {
+            const uint32_t li = cur + 1u;
+            const bool has_l = li < ca; // ca = end of this subtree
+            const bool has_r = cr < ca;
+            const uint32_t ri = has_r ? cr : cur;
+            const float4* __restrict__ ql = reinterpret_cast<const float4*>(kd + (has_l ? li : cur));
+            const float4* __restrict__ qr = reinterpret_cast<const float4*>(kd + ri);
+            const float4 lh = ql[0], ly = ql[2], lz = ql[3];
+            const float4 rh = qr[0], ry = qr[2], rz = qr[3];
+            // the one new plane: both children's boxes are this node's box cut at `cs` on axis k
+            const uint32_t k = cb >> 30;
+            const float ok = k == 0u ? o.x : (k == 1u ? o.y : o.z);
+            const float dk = k == 0u ? d.x : (k == 1u ? d.y : d.z);
+            const float ts = (cs - ok) / dk;
+            const float L2 = k == 0u ? ts : T2, L4 = k == 1u ? ts : T4, L6 = k == 2u ? ts : T6; // left: max plane moved
+            const float R1 = k == 0u ? ts : T1, R3 = k == 1u ? ts : T3, R5 = k == 2u ? ts : T5; // right: min plane moved
+            float bl, br;
+            const bool el = has_l && slab_decide(T1, L2, T3, L4, T5, L6) && !kd_prune(ly, lz, o, inv, oabs, best_d, bl);
+            const bool er = has_r && slab_decide(R1, T2, R3, T4, R5, T6) && !kd_prune(ry, rz, o, inv, oabs, best_d, br);
+            const bool right_first = ((neg >> k) & 1u) != 0u;
+            const bool take_r = er && (right_first || !el);
+            if (el && er && sp < kKdStack) {
+                stack_i[sp] = take_r ? li : ri;
+                stack_t[sp] = take_r ? bl : br;
+                ++sp;
+            }
+            if (el || er) {
+                cur = take_r ? ri : li;
+                ca = __float_as_uint(take_r ? rh.x : lh.x);
+                cb = __float_as_uint(take_r ? rh.y : lh.y);
+                cr = __float_as_uint(take_r ? rh.z : lh.z);
+                cs = take_r ? rh.w : lh.w;
+                T1 = take_r ? R1 : T1; T2 = take_r ? T2 : L2;
+                T3 = take_r ? R3 : T3; T4 = take_r ? T4 : L4;
+                T5 = take_r ? R5 : T5; T6 = take_r ? T6 : L6;
             } else {
-                const uint32_t right = __float_as_uint(t1.w);
-                const bool has_right = right < a; // a = end of this subtree
-                const bool right_first = has_right && ((neg >> __float_as_uint(t0.w)) & 1u) != 0u;
-                next = right_first ? right : cur + 1u;
-                if (has_right && sp < kKdStack) stack[sp++] = right_first ? cur + 1u : right;
+                pop();
             }
         }
-        if (next == none && sp > 0) next = stack[--sp];
-        cur = next;
+        if (cur != none) {
+            leaf_triangles(S, mesh.leaf_base + ca, cb & kKdCountMask, o, d, best_d, best_slot, found, bar_out, p_out);
+            pop();
+        }
     }
 }
 
@@ -311,12 +394,12 @@ __device__ __forceinline__ bool mesh_traverse_lane(const DScene& S, const DMesh 
     if (PRUNE) {
         // a one-leaf mesh whose root the caller already entered needs no walk at all
         const bool flat = work && entered_root && mesh.kd_count == 1u;
-        if (flat) leaf_triangles(S, mesh.leaf_base + kd->a, kd->b, o, d, best_d, best_slot, found, bar_out, p_out);
+        if (flat) leaf_triangles(S, mesh.leaf_base + kd->a, kd->b_axis & kKdCountMask, o, d, best_d, best_slot, found, bar_out, p_out);
         kd_walk_pruned(S, mesh, o, d, work && !flat, best_d, best_slot, found, bar_out, p_out);
     } else {
         uint32_t start = work ? 0u : mesh.kd_count;
         if (work && entered_root) {
-            const uint32_t a = kd->a, b = kd->b;
+            const uint32_t a = kd->a, b = kd->b_axis & kKdCountMask;
             if (b != 0u) leaf_triangles(S, mesh.leaf_base + a, b, o, d, best_d, best_slot, found, bar_out, p_out);
             start = 1u; // a leaf root has kd_count == 1
         }
@@ -339,11 +422,11 @@ __device__ __forceinline__ bool mesh_intersect(const DScene& S, const DMesh mesh
         int best_slot = 0x7FFFFFFF;
         bool found = false;
         const DKdNode* __restrict__ kn = S.kd + mesh.kd_base;
-        const bool inside = lane_on && box_intersect(kn->bmin[0], kn->bmin[1], kn->bmin[2], kn->bmax[0], kn->bmax[1],
-                                                     kn->bmax[2], o, d);
+        const bool inside = lane_on && box_intersect(kn->cmin[0], kn->cmin[1], kn->cmin[2], kn->cmax[0], kn->cmax[1],
+                                                     kn->cmax[2], o, d);
         if (__builtin_amdgcn_ballot_w64(inside) != 0ull) {
             const uint32_t first = mesh.leaf_base + kn->a;
-            const uint32_t count = kn->b;
+            const uint32_t count = kn->b_axis & kKdCountMask;
             for (uint32_t k = 0; k < count; ++k) {
                 const float4* t = S.tri_hit + (size_t)(first + k) * 4;
                 const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
@@ -463,9 +546,9 @@ __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, 
                 }
             } else {
                 const DMesh mesh = S.meshes[nd->mesh];
-                const DKdNode kn = S.kd[mesh.kd_base];
-                const bool inside = lane_on && box_intersect(kn.bmin[0], kn.bmin[1], kn.bmin[2], kn.bmax[0],
-                                                             kn.bmax[1], kn.bmax[2], lo, ld);
+                const DKdNode* __restrict__ kn = S.kd + mesh.kd_base;
+                const bool inside = lane_on && box_intersect(kn->cmin[0], kn->cmin[1], kn->cmin[2], kn->cmax[0],
+                                                             kn->cmax[1], kn->cmax[2], lo, ld);
                 pending |= inside ? (1u << (n - g)) : 0u;
             }
         }

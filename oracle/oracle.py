@@ -50,8 +50,15 @@ def load():
         lib.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]
         lib.orc_secondary_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.orc_set_walk_model.argtypes = [C.c_int]
         _lib = lib
     return _lib
+
+
+def set_walk_model(model):
+    """0 = the reference's visit-everything KD walk (default), 1 = the model of the library's pruned
+    near-first walk (same results by construction; used for equality tests and traffic counts)."""
+    load().orc_set_walk_model(int(model))
 
 
 STAT_NAMES = ["kd_box", "tri_a", "tri_b", "tri_full", "tri_hit", "sphere", "sphere_hit", "node", "node_hit", "ray",

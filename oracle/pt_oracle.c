@@ -105,6 +105,10 @@ typedef struct kd_node {
     tri_t* tris;            /* by-value copies, scene.cpp:222-223,274 */
     uint64_t ntris;
     struct kd_node *left, *right;
+    /* Only for the model of the library's pruned walk (below): padded box of the triangles
+     * under this node and the DFS position of its first leaf triangle.  Not in the reference. */
+    float tmin[3], tmax[3];
+    uint64_t first_slot;
 } kd_node;
 
 typedef struct {
@@ -221,14 +225,97 @@ static void mesh_intersect_internal(const ray_t* r, const kd_node* node, hit_t* 
     }
 }
 
+/* ---- model of the LIBRARY's pruned KD walk (not reference code) ----------------
+ * Restates, on the pointer tree, what kd_walk_pruned in pathtracing_amd/csrc/ptk_device.h
+ * does: enter a node only if the reference's box test passes, near child first by the sign
+ * of the direction on the split axis, skip subtrees whose padded triangle box is missed,
+ * behind, or farther than the best hit, lowest DFS slot wins exact ties.  It exists so that
+ * (a) tests can check on the CPU, over millions of rays, that this walk returns exactly what
+ * mesh_intersect_internal returns, and (b) bench.py can count the nodes and triangles the
+ * walk touches (the algorithmic bytes of the HBM roofline).  orc_set_walk_model(1) makes
+ * every entry point of this file use it. */
+static int g_walk_model = 0;
+void orc_set_walk_model(int model) { g_walk_model = model; }
+
+typedef struct {
+    v3 inv;
+    float oabs;
+    uint32_t neg;
+    float best_d;
+    uint64_t best_slot;
+    hit_t best;
+} walk_t;
+
+static int model_prune(const kd_node* n, const ray_t* r, const walk_t* w, float* bound)
+{
+    const float ax = (n->tmin[0] - r->o.x) * w->inv.x, bx = (n->tmax[0] - r->o.x) * w->inv.x;
+    const float ay = (n->tmin[1] - r->o.y) * w->inv.y, by = (n->tmax[1] - r->o.y) * w->inv.y;
+    const float az = (n->tmin[2] - r->o.z) * w->inv.z, bz = (n->tmax[2] - r->o.z) * w->inv.z;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const int missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)) + 2.0f * w->oabs;
+    const int behind = t_out < 0.0f && t_out * 0.99999f < -w->oabs;
+    const float near_lo = t_in * 0.99999f - w->oabs;
+    *bound = near_lo > 0.0f ? near_lo * near_lo : 0.0f;
+    return missed || behind || *bound > w->best_d;
+}
+
+static void model_walk(const ray_t* r, const kd_node* node, walk_t* w, uint64_t* stats)
+{
+    if (node->ntris || (!node->left && !node->right)) {
+        for (uint64_t i = 0; i < node->ntris; ++i) {
+            if (stats) stats[1]++;
+            hit_t h = tri_intersect(r, &node->tris[i]);
+            if (!h.hit) continue;
+            const v3 dv = sub3(r->o, h.position);
+            const float d = dot3(dv, dv);
+            const uint64_t slot = node->first_slot + i;
+            if (d < w->best_d || (d == w->best_d && slot < w->best_slot)) {
+                w->best = h;
+                w->best_d = d;
+                w->best_slot = slot;
+            }
+        }
+        return;
+    }
+    const kd_node* kid[2] = { node->left, node->right };
+    int enter[2] = { 0, 0 };
+    float bound[2] = { 0.0f, 0.0f };
+    for (int c = 0; c < 2; ++c) {
+        if (!kid[c]) continue;
+        if (stats) stats[0]++;
+        STAT(ST_KD_BOX);
+        enter[c] = box_intersect(kid[c]->bmin, kid[c]->bmax, r) && !model_prune(kid[c], r, w, &bound[c]);
+    }
+    const int first = ((w->neg >> (node->depth % 3)) & 1u) ? 1 : 0; /* right first when the direction is negative */
+    const int second = 1 - first;
+    if (enter[first]) model_walk(r, kid[first], w, stats);
+    if (enter[second] && !(bound[second] > w->best_d)) model_walk(r, kid[second], w, stats);
+}
+
 /* scene.cpp:115-121  mesh::intersect */
 static hit_t mesh_intersect(const mesh_t* m, const ray_t* r, uint64_t* stats)
 {
     hit_t res;
     res.hit = 0;
     float distance = 3.402823466e+38f;
-    mesh_intersect_internal(r, m->root, &res, &distance, stats);
-    return res;
+    if (g_walk_model == 0) {
+        mesh_intersect_internal(r, m->root, &res, &distance, stats);
+        return res;
+    }
+    walk_t w;
+    w.inv = V3(1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z);
+    w.oabs = 1e-5f * (fabsf(r->o.x) + fabsf(r->o.y) + fabsf(r->o.z)) + 1e-30f;
+    w.neg = (r->d.x < 0.0f ? 1u : 0u) | (r->d.y < 0.0f ? 2u : 0u) | (r->d.z < 0.0f ? 4u : 0u);
+    w.best_d = distance;
+    w.best_slot = ~0ull;
+    w.best.hit = 0;
+    float bound;
+    if (stats) stats[0]++;
+    STAT(ST_KD_BOX);
+    if (box_intersect(m->root->bmin, m->root->bmax, r) && !model_prune(m->root, r, &w, &bound))
+        model_walk(r, m->root, &w, stats);
+    return w.best;
 }
 
 /* scene.cpp:401-441  sphere::intersect */
@@ -315,6 +402,45 @@ static void kd_free(kd_node* n)
     free(n);
 }
 
+/* Walk-model annotations (see model_walk): DFS slot numbers and padded triangle boxes,
+ * same padding as fill_triangle_boxes in pathtracing_amd/csrc/kd_build.cpp. */
+static void kd_annotate(kd_node* n, uint64_t* slot)
+{
+    const float big = 3.402823466e+38f;
+    for (int a = 0; a < 3; ++a) { n->tmin[a] = big; n->tmax[a] = -big; }
+    n->first_slot = *slot;
+    *slot += n->ntris;
+    for (uint64_t i = 0; i < n->ntris; ++i)
+        for (int v = 0; v < 3; ++v)
+            for (int a = 0; a < 3; ++a) {
+                const float p = n->tris[i].v[v].position[a];
+                if (p < n->tmin[a]) n->tmin[a] = p;
+                if (p > n->tmax[a]) n->tmax[a] = p;
+            }
+    kd_node* kid[2] = { n->left, n->right };
+    for (int c = 0; c < 2; ++c) {
+        if (!kid[c]) continue;
+        kd_annotate(kid[c], slot);
+    }
+    /* children are padded already; take the union before padding this node */
+    for (int c = 0; c < 2; ++c) {
+        if (!kid[c]) continue;
+        for (int a = 0; a < 3; ++a) {
+            if (kid[c]->tmin[a] < n->tmin[a]) n->tmin[a] = kid[c]->tmin[a];
+            if (kid[c]->tmax[a] > n->tmax[a]) n->tmax[a] = kid[c]->tmax[a];
+        }
+    }
+    if (n->ntris || (!n->left && !n->right))
+        for (int a = 0; a < 3; ++a) {
+            if (!(n->tmin[a] <= n->tmax[a])) continue;
+            const float ext = n->tmax[a] - n->tmin[a];
+            const float mag = fmaxf(fabsf(n->tmin[a]), fabsf(n->tmax[a]));
+            const float pad = 1e-4f * ext + 1e-5f * mag + 1e-30f;
+            n->tmin[a] -= pad;
+            n->tmax[a] += pad;
+        }
+}
+
 /* scene.cpp:123-140  mesh::compile (bounds grow from the default (0,0,0) box, scene.h:67) */
 static void mesh_compile(mesh_t* m)
 {
@@ -329,6 +455,8 @@ static void mesh_compile(mesh_t* m)
             }
     }
     m->root = kd_build(m->tris, m->ntris, m->bmin, m->bmax, 0);
+    uint64_t slot = 0;
+    kd_annotate(m->root, &slot);
 }
 
 /* ---- samplers -------------------------------------------------------------- */

@@ -248,3 +248,29 @@ def test_room_against_reference_png():
     assert np.all(rel < 0.035), rel
     # per texel the 1024-spp side is dominated by Monte-Carlo noise (radiance-25 light, ~16 % median)
     assert np.median(np.abs(a - b) / (b + 0.05)) < 0.3
+
+
+@pytest.mark.parametrize("name,lo,hi,n", [("mario", -8, 8, 150_000), ("room", -10, 10, 100_000)])
+def test_pruned_walk_model_equals_reference_walk(name, lo, hi, n):
+    """The oracle's model of the library's pruned near-first KD walk must return exactly what
+    the reference's visit-everything recursion returns — every output bit — while touching fewer nodes."""
+    from conftest import get_oracle, random_rays
+    from oracle import oracle as O
+    ora = get_oracle(name)
+    o, d = random_rays(n, 4242, lo, hi)
+    pix = np.arange(40_000, dtype=np.uint32) % (128 * 128)
+    so, sd, valid = ora.secondary_rays(128, 128, np.pi / 4, 9, pix, np.arange(40_000, dtype=np.uint64) // 3)
+    o = np.concatenate([o, so[valid]])
+    d = np.concatenate([d, sd[valid]])
+    try:
+        O.set_walk_model(0)
+        ref = ora.intersect_batch(o, d, stats=True)
+        O.set_walk_model(1)
+        mod = ora.intersect_batch(o, d, stats=True)
+    finally:
+        O.set_walk_model(0)
+    for k in ("node", "prim", "t", "u", "v", "position", "normal", "uv"):
+        assert np.array_equal(ref[k], mod[k]), k
+    assert mod["kd_nodes_tested"] <= ref["kd_nodes_tested"] and mod["tris_tested"] <= ref["tris_tested"]
+    if name == "mario":
+        assert mod["tris_tested"] < 0.4 * ref["tris_tested"]

@@ -60,32 +60,48 @@ def flops_from_stats(st, costs, equirect):
     return f
 
 
-def cpu_baseline(scene, target_seconds=12.0):
-    """The CPU restatement of the reference ("port"), timed on this box's host cores on a
-    bounded sample of the same workload (Room 256x256, fewer samples per pixel)."""
+def cpu_baseline(scene, workload, target_seconds=12.0):
+    """The CPU restatement of the reference ("port"), timed on this box's host cores on a bounded
+    sample of the same workload (same scene and resolution, fewer samples per pixel).  Also returns
+    the operation counts the roofline needs: flops per ray from the reference-order run, and the
+    nodes / triangles / texels per ray of the library's pruned KD walk (oracle walk model 1)."""
     import numpy as np
     from oracle import oracle
     ora = oracle.OracleScene(scene)
     # the GPU box's CPU share is 16; os.cpu_count() shows the whole machine there
     cores = min(16, os.cpu_count() or 1)
     cores = int(os.environ.get("PTK_BENCH_CPU_THREADS", cores))
+    sw, sh = min(W, 512), min(H, 512)   # bounded sample: at most 512x512 of the frame's field of view
     t0 = time.perf_counter()
-    ora.render_samples(W, H, FOV, 0, 0, 4, threads=cores)
+    ora.render_samples(sw, sh, FOV, 0, 0, 1, threads=cores)
     probe = time.perf_counter() - t0
-    spp = int(max(4, min(4096, 4 * target_seconds / max(probe, 1e-3))))
+    spp = int(max(1, min(4096, target_seconds / max(probe, 1e-3))))
     t0 = time.perf_counter()
-    _, rays, st = ora.render_samples_stats(W, H, FOV, 0, 0, spp, threads=cores)
+    _, rays, st = ora.render_samples_stats(sw, sh, FOV, 0, 0, spp, threads=cores)
     dt = time.perf_counter() - t0
     with open(os.path.join(ROOT, "tests", "golden", "flop_costs.json")) as f:
         costs = json.load(f)
-    flops = flops_from_stats(st, costs, equirect=False)
-    paths = W * H * spp
+    from pathtracing_amd import scene as S
+    flops = flops_from_stats(st, costs, equirect=isinstance(scene.background, S.EquirectangularMap))
+    paths = sw * sh * spp
+    try:
+        oracle.set_walk_model(1)
+        _, mrays, mst = ora.render_samples_stats(sw, sh, FOV, 0, 0, max(1, spp // 8), threads=cores)
+    finally:
+        oracle.set_walk_model(0)
+    # algorithmic HBM bytes per ray of the GPU path (DESIGN.md "Roofline"): 64 B per KD node tested,
+    # 64 B per triangle hit record, 64 B shading record per triangle winner, 12 B per texel, and the
+    # SoA ray record in + out (52 + 52 B)
+    bytes_per_ray = (64 * mst["kd_box"] + 64 * mst["tri_a"] + 64 * mst["mesh_win"] + 12 * mst["texel"]) / mrays + 104
     return {
         "value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
-        "sample": f"room.json {W}x{H}, {spp} spp ({paths} paths, {rays} rays) in {dt:.1f} s, oracle/pt_oracle.c, "
-                  f"{cores} pthreads; the reference itself is unbuildable here (glm/spdlog absent)",
+        "sample": f"{WORKLOADS[workload]['desc']}; {sw}x{sh}, {spp} spp ({paths} paths, {rays} rays) in {dt:.1f} s, "
+                  f"oracle/pt_oracle.c, {cores} pthreads; the reference itself is unbuildable here (glm/spdlog absent)",
         "mrays_per_s": rays / dt / 1e6,
-    }, flops / rays, rays / paths
+    }, {"flops_per_ray": flops / rays, "bytes_per_ray": bytes_per_ray,
+        "kd_nodes_per_ray": mst["kd_box"] / mrays, "triangles_per_ray": mst["tri_a"] / mrays,
+        "texels_per_ray": mst["texel"] / mrays,
+        "ref_kd_nodes_per_ray": st["kd_box"] / rays, "ref_triangles_per_ray": st["tri_a"] / rays}
 
 
 def main():
@@ -94,8 +110,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU port for workloads other than room")
     ap.add_argument("--traversal", type=int, default=None, help="PTK_OPT_TRAVERSAL override (0/1), for A/B runs")
     ap.add_argument("--kd-prune", type=int, default=None, help="PTK_OPT_KD_PRUNE override (0/1), for A/B runs")
+    ap.add_argument("--node-cull", type=int, default=None, help="PTK_OPT_NODE_CULL override (0/1/2), for A/B runs")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="room")
     ap.add_argument("--triangles", type=int, default=5_000_000, help="synthetic workload: triangle count")
     ap.add_argument("--resolution", type=int, nargs=2, default=None)
@@ -119,6 +137,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     scene = load_workload(args.workload, args.triangles)
+    drop = os.environ.get("PTK_BENCH_DROP")  # experiment knob: drop nodes by kind ("sphere", "leaf12", ...)
+    if drop:
+        from pathtracing_amd import scene as S
+        keep = []
+        for n in scene.nodes:
+            kind = "sphere" if isinstance(n.shape, S.Sphere) else f"leaf{n.shape.triangles.shape[0]}"
+            if kind not in drop.split(","):
+                keep.append(n)
+        scene.nodes = keep
     ctx = Context(local_rank)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
@@ -126,6 +153,8 @@ def main():
         ctx.set_option(1, args.traversal)
     if args.kd_prune is not None:
         ctx.set_option(2, args.kd_prune)
+    if args.node_cull is not None:
+        ctx.set_option(3, args.node_cull)
     ctx.upload(scene)
     ctx.render_begin(W, H, FOV)
     total = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
@@ -183,34 +212,37 @@ def main():
                        "paths_per_step_per_gpu": W * H * SPI, "rays_per_path": rays / paths,
                        "parallelism": f"sample-range x{world}" + (" + RCCL reduce(sum) to rank 0" if distributed else "")},
         }
-        base = None
-        flops_per_ray = None
-        if not args.no_cpu_baseline and args.workload == "room":
-            base, flops_per_ray, _ = cpu_baseline(scene)
-            out["cpu_baseline"] = base
+        model = None
+        if not args.no_cpu_baseline and (args.workload == "room" or args.cpu_baseline):
+            out["cpu_baseline"], model = cpu_baseline(scene, args.workload)
         else:
             out["cpu_baseline"] = None
         # dominant kernel: k_bounce<false> (bounces 1..4), rank 0's launches
         n_launch, ms = timing["k_bounce<false>"]
         n0, ms0 = timing["k_bounce<true>"]
-        if n_launch and flops_per_ray is not None:
-            rays_rank0 = rays / world
-            paths_rank0 = paths / world
-            rays_next = rays_rank0 - paths_rank0           # rays cast by the k_bounce<false> launches
-            flops_per_launch = flops_per_ray * rays_next / n_launch
+        if n_launch and model is not None:
+            rays_next = (rays - paths) / world / n_launch          # rays cast per k_bounce<false> launch
             avg_ms = ms / n_launch
-            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            queue_bytes = (52 + 52) * rays_next / n_launch   # SoA ray record in + out
-            out["roofline"] = {
-                "bound": "valu", "kernel": "k_bounce<false>", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                "avg_launch_ms": avg_ms, "launches": n_launch, "flops_per_ray": flops_per_ray,
-                "rays_per_launch": rays_next / n_launch,
-                "hbm_algorithmic_GBs": queue_bytes / (avg_ms * 1e-3) / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
-                "first_bounce_avg_ms": (ms0 / n0) if n0 else None,
-                "note": "no MFMA on this path; peak = fp32 vector FMA peak, while hit arithmetic is built unfused "
-                        "(-ffp-contract=off, bit-exact ids) so 78.6 T un-fused op/s is the reachable ceiling",
-            }
+            tflops = model["flops_per_ray"] * rays_next / (avg_ms * 1e-3) / 1e12
+            gbs = model["bytes_per_ray"] * rays_next / (avg_ms * 1e-3) / 1e9
+            common = {"kernel": "k_bounce<false>", "traffic": None, "avg_launch_ms": avg_ms, "launches": n_launch,
+                      "rays_per_launch": rays_next, "first_bounce_avg_ms": (ms0 / n0) if n0 else None, **model}
+            if args.workload in ("room", "spheres"):
+                # scene is scalar-cache resident: VALU issue bounds the kernel, not HBM
+                out["roofline"] = {
+                    "bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / PEAK_FP32_TFLOPS, **common,
+                    "hbm_algorithmic_GBs": gbs, "hbm_peak_GBs": PEAK_HBM_GBS,
+                    "note": "no MFMA on this path; peak = fp32 vector FMA peak, while hit arithmetic is built unfused "
+                            "(-ffp-contract=off, bit-exact ids) so 78.6 T un-fused op/s is the reachable ceiling",
+                }
+            else:
+                out["roofline"] = {
+                    "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    **common, "valu_algorithmic_TFLOPs": tflops,
+                    "note": "algorithmic bytes of the pruned KD walk (oracle walk model); divergent per-lane traversal "
+                            "keeps the kernel VALU/latency-bound well below the HBM roof (profiles/)",
+                }
         else:
             out["roofline"] = None
         print(json.dumps(out), flush=True)

@@ -62,7 +62,7 @@ def set_walk_model(model):
 
 
 STAT_NAMES = ["kd_box", "tri_a", "tri_b", "tri_full", "tri_hit", "sphere", "sphere_hit", "node", "node_hit", "ray",
-              "shade", "miss", "path", "mesh_win"]
+              "shade", "miss", "path", "mesh_win", "texel"]
 
 
 class OracleScene:

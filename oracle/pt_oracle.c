@@ -49,6 +49,7 @@ enum {
     ST_MISS = 11,      /* rays that sampled the background                   */
     ST_PATH = 12,      /* primary rays generated                             */
     ST_MESH_WIN = 13,  /* rays whose closest hit is a triangle               */
+    ST_TEXEL = 14,     /* texels read by image::sample (4 per linear lookup) */
     ST_COUNT = 16
 };
 static __thread uint64_t* tl_stats = 0;
@@ -479,6 +480,7 @@ static v3 image_sample(const tex_t* t, uint32_t mode, v2 uv)
     const float v0 = uv.y - floorf(uv.y);
     const float x = u0 * (float)t->w;
     const float y = v0 * (float)t->h;
+    if (tl_stats) tl_stats[ST_TEXEL] += (mode == PTK_MODE_LINEAR) ? 4 : 1;
     if (mode == PTK_MODE_LINEAR) {
         const uint32_t x0 = (uint32_t)floorf(x) % t->w;
         const uint32_t x1 = (uint32_t)ceilf(x) % t->w;

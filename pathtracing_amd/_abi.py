@@ -110,6 +110,7 @@ class KernelTiming(C.Structure):
 
 PTK_OPT_TRAVERSAL = 1
 PTK_OPT_KD_PRUNE = 2
+PTK_OPT_NODE_CULL = 3
 PTK_KERNEL_NAMES = ["k_bounce<true>", "k_bounce<false>", "k_accumulate", "k_intersect_batch"]
 
 # name -> (restype, argtypes); every symbol include/ptk.h declares.

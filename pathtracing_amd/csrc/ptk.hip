@@ -330,6 +330,7 @@ struct ptk_ctx {
 
     int traversal = 2; // PTK_OPT_TRAVERSAL
     int kd_prune = 1;  // PTK_OPT_KD_PRUNE
+    int node_cull = 2; // PTK_OPT_NODE_CULL
     bool deep_kd = false; // some mesh has more than one KD node (the pruned walk only pays off then)
 
     // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
@@ -424,6 +425,67 @@ void make_shade_record(const ptk_triangle& t, float4* s)
     s[3] = make_float4(t.v[1].uv[1], t.v[2].uv[0], t.v[2].uv[1], 0.0f);
 }
 
+// Conservative world-space bounds of a node for the per-lane candidate lists
+// (intersect_scene_lanelist, ptk_device.h).  lo/hi: the node's local box (mesh::m_bounds or the
+// unit ball's box).  All in double from the fp32 matrices the caller supplied.  The margin
+// coefficient is 256 x (fp32 epsilon x condition number) + 4 x the measured inconsistency of
+// transform * inv_transform; matrices that are ill-conditioned, inconsistent or not finite
+// switch the test off for the node (infinite box), which is always correct.
+void make_cull_bounds(const ptk_node_desc& n, const float lo[3], const float hi[3], DNode& d)
+{
+    const float big = 3.402823466e+38f;
+    auto disable = [&]() {
+        for (int a = 0; a < 3; ++a) {
+            d.wmin[a] = -big;
+            d.wmax[a] = big;
+        }
+        d.cull_k = 0.0f;
+        d.cull_c = 0.0f;
+    };
+    const float* M = n.transform;      // column-major: M[c*4+r]
+    const float* I = n.inv_transform;
+    double fa = 0.0, fi = 0.0, incons = 0.0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            fa += (double)M[c * 4 + r] * M[c * 4 + r];
+            fi += (double)I[c * 4 + r] * I[c * 4 + r];
+            double e = (r == c) ? -1.0 : 0.0;
+            for (int k = 0; k < 3; ++k) e += (double)M[k * 4 + r] * I[c * 4 + k];
+            incons = std::fmax(incons, std::fabs(e));
+        }
+    double tmag = 0.0, tres = 0.0;
+    for (int r = 0; r < 3; ++r) {
+        double e = M[12 + r];
+        for (int k = 0; k < 3; ++k) e += (double)M[k * 4 + r] * I[12 + k];
+        tres = std::fmax(tres, std::fabs(e));
+        tmag = std::fmax(tmag, std::fabs((double)M[12 + r]));
+    }
+    const double cond = std::sqrt(fa) * std::sqrt(fi);
+    const double k = 256.0 * 1.1920928955078125e-7 * cond + 4.0 * incons;
+    if (!(cond == cond) || !std::isfinite(cond) || !(k < 0.02) || !(tres <= 1e-3 * (tmag + 1.0))) return disable();
+    double wlo[3] = { 1e300, 1e300, 1e300 }, whi[3] = { -1e300, -1e300, -1e300 };
+    for (int corner = 0; corner < 8; ++corner) {
+        const double p[3] = { (corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2] };
+        for (int r = 0; r < 3; ++r) {
+            const double w = M[0 * 4 + r] * p[0] + M[1 * 4 + r] * p[1] + M[2 * 4 + r] * p[2] + M[12 + r];
+            wlo[r] = std::fmin(wlo[r], w);
+            whi[r] = std::fmax(whi[r], w);
+        }
+    }
+    double mag = 0.0;
+    for (int r = 0; r < 3; ++r) {
+        if (!std::isfinite(wlo[r]) || !std::isfinite(whi[r])) return disable();
+        mag = std::fmax(mag, std::fmax(std::fabs(wlo[r]), std::fabs(whi[r])) + (whi[r] - wlo[r]));
+    }
+    if (!(mag < 1e30)) return disable();
+    for (int r = 0; r < 3; ++r) {
+        d.wmin[r] = std::nextafter((float)wlo[r], -big); // round outwards
+        d.wmax[r] = std::nextafter((float)whi[r], big);
+    }
+    d.cull_k = (float)k;
+    d.cull_c = (float)(k * (mag + tres) + 4.0 * tres) + 1e-30f;
+}
+
 constexpr size_t kMaxStamps = 8192;
 
 // Brackets one kernel launch with HIP events on the context's stream when timing is on.
@@ -457,6 +519,17 @@ void drop_stamps(ptk_ctx* c)
         (void)hipEventDestroy(s.b);
     }
     c->stamps.clear();
+}
+
+// Template MODE of the cast kernels (ptk_device.h, intersect_scene_mode) for this context / scene.
+// `primary`: the coherent camera rays of bounce 0.
+constexpr uint32_t kCullMinNodes = 16; // PTK_OPT_NODE_CULL = 2: candidate lists from this many nodes on
+int kernel_mode(const ptk_ctx* c, bool primary)
+{
+    const bool cull = c->node_cull == 1 || (c->node_cull == 2 && c->S.num_nodes >= kCullMinNodes);
+    // PTK_OPT_TRAVERSAL = 2: primary rays walk every node together unless the cull pays off
+    const bool lists = c->traversal == 1 || (c->traversal == 2 && (!primary || cull));
+    return (lists ? 1 : 0) | ((c->kd_prune && c->deep_kd) ? 2 : 0) | ((lists && cull) ? 4 : 0);
 }
 
 int set_device(ptk_ctx* c)
@@ -636,6 +709,15 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         d.emission = n.emission;
         d.roughness = n.roughness;
         d.metallic = n.metallic;
+        const float unit_lo[3] = { -1.0f, -1.0f, -1.0f }, unit_hi[3] = { 1.0f, 1.0f, 1.0f };
+        if (n.shape_kind == PTK_SHAPE_MESH) {
+            const ptk_kd_info& ki = c->kd_infos[n.mesh];
+            make_cull_bounds(n, ki.bmin, ki.bmax, d);
+            d.cls = ki.num_nodes > 1 ? kClassTree : (ki.num_leaf_prims <= kSmallLeafMax ? kClassSmallLeaf : kClassLeaf);
+        } else {
+            make_cull_bounds(n, unit_lo, unit_hi, d);
+            d.cls = kClassSphere;
+        }
     }
     std::vector<DSampler> samplers(sc->num_samplers);
     for (uint32_t i = 0; i < sc->num_samplers; ++i) {
@@ -718,14 +800,17 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
     const uint32_t blocks = (uint32_t)((n + kBlock - 1) / kBlock);
     {
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
-        const int mode = (c->traversal >= 1 ? 1 : 0) | ((c->kd_prune && c->deep_kd) ? 2 : 0);
         const dim3 g(blocks), b(kBlock);
-        switch (mode) {
-        case 0: k_intersect_batch<0><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv); break;
-        case 1: k_intersect_batch<1><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv); break;
-        case 2: k_intersect_batch<2><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv); break;
-        default: k_intersect_batch<3><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv); break;
+#define PTK_BATCH(M) k_intersect_batch<M><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv)
+        switch (kernel_mode(c, false)) {
+        case 0: PTK_BATCH(0); break;
+        case 1: PTK_BATCH(1); break;
+        case 2: PTK_BATCH(2); break;
+        case 3: PTK_BATCH(3); break;
+        case 5: PTK_BATCH(5); break;
+        default: PTK_BATCH(7); break;
         }
+#undef PTK_BATCH
     }
     PTK_HIP(c, hipGetLastError());
     return PTK_OK;
@@ -852,27 +937,32 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
             A.sample_begin = sample_begin + s0;
             A.seed = seed;
             A.bounce = 0;
-            const int prune_bit = (c->kd_prune && c->deep_kd) ? 2 : 0;
             const dim3 grid(A.num_segments), block(kBlock);
+#define PTK_BOUNCE(F, M) k_bounce<F, M><<<grid, block, 0, c->stream>>>(c->S, c->V, A)
             {
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
-                switch ((c->traversal == 1 ? 1 : 0) | prune_bit) {
-                case 0: k_bounce<true, 0><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
-                case 1: k_bounce<true, 1><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
-                case 2: k_bounce<true, 2><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
-                default: k_bounce<true, 3><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                switch (kernel_mode(c, true)) {
+                case 0: PTK_BOUNCE(true, 0); break;
+                case 1: PTK_BOUNCE(true, 1); break;
+                case 2: PTK_BOUNCE(true, 2); break;
+                case 3: PTK_BOUNCE(true, 3); break;
+                case 5: PTK_BOUNCE(true, 5); break;
+                default: PTK_BOUNCE(true, 7); break;
                 }
             }
             for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) {
                 A.bounce = b;
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_NEXT);
-                switch ((c->traversal >= 1 ? 1 : 0) | prune_bit) {
-                case 0: k_bounce<false, 0><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
-                case 1: k_bounce<false, 1><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
-                case 2: k_bounce<false, 2><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
-                default: k_bounce<false, 3><<<grid, block, 0, c->stream>>>(c->S, c->V, A); break;
+                switch (kernel_mode(c, false)) {
+                case 0: PTK_BOUNCE(false, 0); break;
+                case 1: PTK_BOUNCE(false, 1); break;
+                case 2: PTK_BOUNCE(false, 2); break;
+                case 3: PTK_BOUNCE(false, 3); break;
+                case 5: PTK_BOUNCE(false, 5); break;
+                default: PTK_BOUNCE(false, 7); break;
                 }
             }
+#undef PTK_BOUNCE
             const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
             {
                 LaunchTimer lt(c, PTK_KERNEL_ACCUMULATE);
@@ -960,6 +1050,10 @@ int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
     if (!c) return PTK_ERR_INVALID;
     if (option == PTK_OPT_TRAVERSAL && value >= 0 && value <= 2) {
         c->traversal = value;
+        return PTK_OK;
+    }
+    if (option == PTK_OPT_NODE_CULL && value >= 0 && value <= 2) {
+        c->node_cull = value;
         return PTK_OK;
     }
     if (option == PTK_OPT_KD_PRUNE && (value == 0 || value == 1)) {

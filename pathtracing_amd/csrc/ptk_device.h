@@ -24,8 +24,18 @@ struct alignas(16) DNode {
     float nrm[16]; // scene_node::m_normal_transform (scene.h:290)
     uint32_t kind, mesh;
     uint32_t albedo, emission, roughness, metallic;
-    uint32_t pad[10];
+    // Conservative world-space bounds of everything the node can be hit at (host: make_cull_bounds
+    // in ptk.hip).  A ray that misses [wmin - m, wmax + m] with m = cull_k * |o|_1 + cull_c cannot be
+    // reported as hitting this node by the reference's local-space tests; see intersect_scene_lanelist.
+    float wmin[3], wmax[3];
+    float cull_k, cull_c;
+    // Work class for the per-lane candidate loops: lanes of a wave run in lockstep, so candidates
+    // are processed class by class to keep the triangle-loop trip counts alike (kClass*).
+    uint32_t cls;
+    uint32_t pad[1];
 };
+enum { kClassSphere = 0, kClassSmallLeaf = 1, kClassLeaf = 2, kClassTree = 3, kNumClasses = 4 };
+constexpr uint32_t kSmallLeafMax = 4u; // a one-leaf mesh with at most this many triangles (plane.obj: 2)
 static_assert(sizeof(DNode) == 256, "DNode must be 256 B");
 
 // Flattened KD node, 64 B = four 16-B words:
@@ -496,17 +506,25 @@ __device__ __forceinline__ void intersect_scene(const DScene& S, V3 o, V3 d, boo
     }
 }
 
-// ---- traversal mode 1: per-lane node lists ------------------------------------
-// In scenes like Room every ray tests every node, but a ray pierces the root box
-// of only ~1.4 of the 8 mesh nodes, so walking each mesh's triangles with the whole
-// wave (mode 0) leaves most lanes idle.  Mode 1 splits cast_ray in two phases:
-//   1. wave-uniform node loop: ray -> local, spheres intersected in place, meshes
-//      only root-box tested; a per-lane bit mask records the meshes to visit;
-//   2. per-lane loop over that mask: every lane takes ITS next mesh node, rebuilds
-//      the same local ray (same operations, same bits) and traverses it.
-// The reference's "first node wins exact ties" (strict < in node order,
-// scene.cpp:386) is kept by an explicit (d0, node index) comparison, so the result
-// does not depend on the processing order.
+// ---- traversal mode 1b: per-lane candidate lists --------------------------------
+// The reference tests every ray against every node (scene.cpp:361): ray -> local (two
+// mat-vecs + a normalise), then the shape.  In scenes like Room a ray can only hit one or
+// two of the ten nodes, so mode 1 splits cast_ray in two phases:
+//   1. wave-uniform loop over the node table: a cheap, CONSERVATIVE world-space slab test
+//      of the ray against each node's padded bounds (DNode::wmin/wmax); a per-lane bit mask
+//      records the nodes that survive;
+//   2. per-lane loops over that mask (spheres, then meshes): every lane takes ITS next
+//      candidate and runs the reference's arithmetic on it: ray -> local, sphere / box +
+//      triangles / KD walk, hit -> world.
+// Phase 1 never decides a hit, it only discards nodes the reference could not report:
+// the reference reports a hit only if its fp32 local-space test passes, i.e. if the ray
+// passes within rounding distance of the node's local box (meshes: mesh::m_bounds, which the
+// root box test enforces, scene.cpp:190; spheres: the unit ball).  Mapped to world space that
+// is the node's world box grown by at most (error of M^-1 and of the fp32 chain) ~
+// cond(M) * 2^-23 * (|o| + |box|); the host stores 256 x that bound as cull_k / cull_c and
+// disables the test (infinite box) for ill-conditioned or inconsistent matrices.
+// The reference's "first node wins exact ties" (strict < in node order, scene.cpp:386) is
+// kept by an explicit (d0, node index) comparison, so processing order does not matter.
 
 __device__ __forceinline__ void best_update(Hit& best, float d0, int n, int prim, V3 a, V3 pw)
 {
@@ -521,8 +539,136 @@ __device__ __forceinline__ void best_update(Hit& best, float d0, int n, int prim
     }
 }
 
+// operator*(mat4, ray) (scene.cpp:18-23) with the matrix read per lane (node differs per lane)
+__device__ __forceinline__ void lane_ray_to_local(const float4* __restrict__ nv, V3 o, V3 d, V3& lo, V3& ld)
+{
+    const float4 i0 = nv[0], i1 = nv[1], i2 = nv[2], i3 = nv[3];
+    lo = mk((i0.x * o.x + i1.x * o.y) + (i2.x * o.z + i3.x * 1.0f),
+            (i0.y * o.x + i1.y * o.y) + (i2.y * o.z + i3.y * 1.0f),
+            (i0.z * o.x + i1.z * o.y) + (i2.z * o.z + i3.z * 1.0f));
+    ld = normalize(mk((i0.x * d.x + i1.x * d.y) + (i2.x * d.z + i3.x * 0.0f),
+                      (i0.y * d.x + i1.y * d.y) + (i2.y * d.z + i3.y * 0.0f),
+                      (i0.z * d.x + i1.z * d.y) + (i2.z * d.z + i3.z * 0.0f)));
+}
+
+// hit -> world (scene.cpp:375) + distance (scene.cpp:383), matrix read per lane
+__device__ __forceinline__ void lane_hit_to_world(const float4* __restrict__ nv, V3 o, V3 p, V3& pw, float& d0)
+{
+    const float4 x0 = nv[4], x1 = nv[5], x2 = nv[6], x3 = nv[7];
+    pw = mk((x0.x * p.x + x1.x * p.y) + (x2.x * p.z + x3.x * 1.0f),
+            (x0.y * p.x + x1.y * p.y) + (x2.y * p.z + x3.y * 1.0f),
+            (x0.z * p.x + x1.z * p.y) + (x2.z * p.z + x3.z * 1.0f));
+    const V3 dv = pw - o;
+    d0 = dot(dv, dv);
+}
+
 template <bool PRUNE>
 __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
+{
+    best.d0 = 3.402823466e+38f;
+    best.node = -1;
+    best.prim = -1;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    best.pw = mk(0.0f, 0.0f, 0.0f);
+    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const float o1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
+    for (uint32_t g = 0; g < S.num_nodes; g += 32u) {
+        const uint32_t gend = (S.num_nodes - g < 32u) ? S.num_nodes : g + 32u;
+        uint32_t pend_sphere = 0u, pend_small = 0u, pend_leaf = 0u, pend_tree = 0u;
+        // phase 1: wave-uniform, conservative
+        for (uint32_t n = g; n < gend; ++n) {
+            const DNode* __restrict__ nd = S.nodes + n;
+            const float m = nd->cull_k * o1 + nd->cull_c;
+            const float ax = ((nd->wmin[0] - m) - o.x) * inv.x, bx = ((nd->wmax[0] + m) - o.x) * inv.x;
+            const float ay = ((nd->wmin[1] - m) - o.y) * inv.y, by = ((nd->wmax[1] + m) - o.y) * inv.y;
+            const float az = ((nd->wmin[2] - m) - o.z) * inv.z, bz = ((nd->wmax[2] + m) - o.z) * inv.z;
+            const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            // false on NaN = keep the node
+            const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out));
+            const bool behind = t_out < 0.0f;
+            const uint32_t bit = (lane_on && !(missed || behind)) ? (1u << (n - g)) : 0u;
+            const uint32_t cls = nd->cls; // wave-uniform
+            if (cls == kClassSphere) pend_sphere |= bit;
+            else if (cls == kClassSmallLeaf) pend_small |= bit;
+            else if (cls == kClassLeaf) pend_leaf |= bit;
+            else pend_tree |= bit;
+        }
+        // phase 2a: spheres
+        while (__builtin_amdgcn_ballot_w64(pend_sphere != 0u) != 0ull) {
+            const bool work = pend_sphere != 0u;
+            const uint32_t n = g + (work ? (uint32_t)__builtin_ctz(pend_sphere) : 0u);
+            pend_sphere &= pend_sphere - 1u;
+            const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + n);
+            V3 lo, ld, p = mk(0.0f, 0.0f, 0.0f);
+            lane_ray_to_local(nv, o, d, lo, ld);
+            if (work && sphere_intersect(lo, ld, p)) {
+                V3 pw;
+                float d0;
+                lane_hit_to_world(nv, o, p, pw, d0);
+                best_update(best, d0, (int)n, -1, p, pw);
+            }
+        }
+        // phase 2b/2c: one-leaf meshes, small ones first (mesh::intersect on a root leaf:
+        // box test, then the leaf's triangles, scene.cpp:190-203)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t& pend = pass == 0 ? pend_small : pend_leaf;
+            while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
+                const bool work = pend != 0u;
+                const uint32_t n = g + (work ? (uint32_t)__builtin_ctz(pend) : 0u);
+                pend &= pend - 1u;
+                const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + n);
+                V3 lo, ld;
+                lane_ray_to_local(nv, o, d, lo, ld);
+                const DMesh mesh = S.meshes[work ? (S.nodes + n)->mesh : 0u];
+                const DKdNode* __restrict__ kn = S.kd + mesh.kd_base;
+                const bool inside = work && box_intersect(kn->cmin[0], kn->cmin[1], kn->cmin[2], kn->cmax[0],
+                                                          kn->cmax[1], kn->cmax[2], lo, ld);
+                float best_d = 3.402823466e+38f;
+                int best_slot = 0x7FFFFFFF;
+                bool found = false;
+                V3 p = mk(0.0f, 0.0f, 0.0f), a = mk(0.0f, 0.0f, 0.0f);
+                const uint32_t count = inside ? (kn->b_axis & kKdCountMask) : 0u;
+                leaf_triangles(S, mesh.leaf_base + kn->a, count, lo, ld, best_d, best_slot, found, a, p);
+                if (found) {
+                    V3 pw;
+                    float d0;
+                    lane_hit_to_world(nv, o, p, pw, d0);
+                    best_update(best, d0, (int)n, best_slot, a, pw);
+                }
+            }
+        }
+        // phase 2d: meshes with a real KD-tree
+        while (__builtin_amdgcn_ballot_w64(pend_tree != 0u) != 0ull) {
+            const bool work = pend_tree != 0u;
+            const uint32_t n = g + (work ? (uint32_t)__builtin_ctz(pend_tree) : 0u);
+            pend_tree &= pend_tree - 1u;
+            const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + n);
+            V3 lo, ld;
+            lane_ray_to_local(nv, o, d, lo, ld);
+            const uint32_t mesh_idx = work ? (S.nodes + n)->mesh : 0u;
+            const DMesh mesh = S.meshes[mesh_idx];
+            int prim = -1;
+            V3 p = mk(0.0f, 0.0f, 0.0f), a = mk(0.0f, 0.0f, 0.0f);
+            if (mesh_traverse_lane<PRUNE>(S, mesh, lo, ld, work, false, prim, a, p)) {
+                V3 pw;
+                float d0;
+                lane_hit_to_world(nv, o, p, pw, d0);
+                best_update(best, d0, (int)n, prim, a, pw);
+            }
+        }
+    }
+}
+
+// ---- traversal mode 1a: per-lane node lists -------------------------------------
+// For scenes with few nodes.  Phase 1 is the reference's node loop run by the whole wave
+// (node matrices come in through scalar loads): ray -> local, spheres intersected in place,
+// meshes only root-box tested (the reference's own test, scene.cpp:190); a per-lane bit mask
+// records the meshes whose root box the lane's ray pierced.  Phase 2: every lane takes ITS
+// next pierced mesh, rebuilds the same local ray (same operations, same bits) and walks it.
+template <bool PRUNE>
+__device__ __forceinline__ void intersect_scene_nodelist(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
 {
     best.d0 = 3.402823466e+38f;
     best.node = -1;
@@ -581,11 +727,13 @@ __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, 
     }
 }
 
-// MODE bit 0: node-loop mapping (PTK_OPT_TRAVERSAL), bit 1: pruned KD walk (PTK_OPT_KD_PRUNE).
+// MODE bit 0: per-lane lists instead of the all-lanes-every-node loop (PTK_OPT_TRAVERSAL), bit 1: pruned KD
+// walk (PTK_OPT_KD_PRUNE), bit 2 (with bit 0): candidate lists after the conservative cull (PTK_OPT_NODE_CULL).
 template <int MODE>
 __device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
 {
-    if (MODE & 1) intersect_scene_lanelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
+    if ((MODE & 5) == 5) intersect_scene_lanelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
+    else if (MODE & 1) intersect_scene_nodelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
     else intersect_scene<(MODE & 2) != 0>(S, o, d, lane_on, best);
 }
 

@@ -182,3 +182,37 @@ def test_synthetic_displaced_sphere(gpu_ctx):
     assert (r["prim"] >= 0).mean() > 0.2
     o, d = random_rays(200_000, 77, -1.6, 1.6)
     check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d))
+
+
+def test_many_random_nodes(gpu_ctx):
+    """40 nodes with random rotations, non-uniform scales (up to 30:1), tiny far-away objects and shared
+    meshes: the conservative world-space node cull (PTK_OPT_NODE_CULL) must never drop a node the reference
+    reports a hit on, whatever the transform."""
+    from oracle import oracle
+    from pathtracing_amd import scene as S
+    rng = np.random.default_rng(2024)
+    sc = S.Scene()
+    cube = get_scene("room").nodes  # borrow the cube / plane meshes
+    meshes = [n.shape for n in cube if isinstance(n.shape, S.Mesh)]
+    small = [meshes[0], meshes[-1], S.Mesh(random_soup(300, 3, extent=1.0, size=0.3))]
+    for i in range(40):
+        node = S.SceneNode()
+        far = 40.0 if i % 7 == 0 else 6.0
+        node.translate(rng.uniform(-far, far, 3).astype(np.float32))
+        axis = rng.normal(0, 1, 3).astype(np.float32)
+        node.rotate(axis, np.float32(rng.uniform(0, 6.28)))
+        base = 0.02 if i % 5 == 0 else rng.uniform(0.3, 2.0)
+        node.scale((base * rng.uniform(1.0, 30.0 if i % 3 == 0 else 1.5, 3)).astype(np.float32))
+        node.shape = S.Sphere() if i % 2 == 0 else small[i % 3]
+        sc.nodes.append(node)
+    ora = oracle.OracleScene(sc)
+    gpu_ctx.upload(sc)
+    o, d = random_rays(300_000, 8, -45, 45)
+    # aim half of the rays at node centres so that the small / thin ones are actually hit
+    centres = np.stack([n.transform[3][:3] for n in sc.nodes]).astype(np.float32)
+    tgt = centres[rng.integers(0, len(centres), len(o) // 2)] + rng.normal(0, 0.3, (len(o) // 2, 3)).astype(np.float32)
+    dd = tgt - o[: len(tgt)]
+    d[: len(tgt)] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
+    g, r = gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d)
+    check_batch(g, r)
+    assert (r["node"] >= 0).mean() > 0.25 and len(np.unique(r["node"])) > 30

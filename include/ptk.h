@@ -252,7 +252,7 @@ int ptk_reset_counters(ptk_ctx* ctx);
  * tested in the uniform loop and each lane then visits only the nodes whose box it pierced;
  * 2 (default) = 0 for the coherent primary rays of bounce 0 (1 if PTK_OPT_NODE_CULL applies), 1 for
  * later bounces and for ptk_intersect_batch.  No reference counterpart. */
-enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3 };
+enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4 };
 /* PTK_OPT_KD_PRUNE: how a multi-node KD-tree is walked (mesh::intersect_internal,
  * scene.cpp:188-212).  0 = the reference's order, every box-hit node is visited;
  * 1 (default) = near child first (by the sign of the ray direction on the split axis),
@@ -261,7 +261,11 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3 };
  * PTK_OPT_NODE_CULL: with per-lane lists (PTK_OPT_TRAVERSAL 1/2), whether the lists are built by a
  * conservative world-space box test per node (1) or by the reference's own local-space root test
  * run by the whole wave (0); 2 (default) = 1 for scenes with at least 16 nodes.  The test only
- * discards nodes the reference cannot report a hit on, so results do not change. */
+ * discards nodes the reference cannot report a hit on, so results do not change.
+ * PTK_OPT_BALANCE: 1 = the (ray, node) pairs that survive the conservative cull, and the triangles
+ * of the one-leaf meshes among them, are pooled per wave in LDS and dealt evenly to its 64 lanes
+ * (overrides PTK_OPT_TRAVERSAL / PTK_OPT_NODE_CULL); 0 = off; 2 (default) = on for scenes with at
+ * least two nodes.  Winners are chosen by the reference's own keys, so results do not change. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptk.so")
+# PTK_LIB: an experiment build of the same library (scripts/), never a different implementation
+LIB_PATH = os.environ.get("PTK_LIB") or os.path.join(_HERE, "libptk.so")
 
 PTK_OK = 0
 PTK_ERR_INVALID, PTK_ERR_HIP, PTK_ERR_STATE, PTK_ERR_NOMEM = 1, 2, 3, 4
@@ -111,6 +112,7 @@ class KernelTiming(C.Structure):
 PTK_OPT_TRAVERSAL = 1
 PTK_OPT_KD_PRUNE = 2
 PTK_OPT_NODE_CULL = 3
+PTK_OPT_BALANCE = 4
 PTK_KERNEL_NAMES = ["k_bounce<true>", "k_bounce<false>", "k_accumulate", "k_intersect_batch"]
 
 # name -> (restype, argtypes); every symbol include/ptk.h declares.

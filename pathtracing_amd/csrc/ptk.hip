@@ -47,13 +47,14 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch(const DScene S, uint
                                                             float* __restrict__ position, float* __restrict__ normal,
                                                             float* __restrict__ uv)
 {
+    __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool on = i < n;
     const uint64_t j = on ? i : 0;
     const V3 ro = mk(o[j], o[n + j], o[2 * n + j]);
     const V3 rd = mk(d[j], d[n + j], d[2 * n + j]);
     Hit h;
-    intersect_scene_mode<MODE>(S, ro, rd, on, h);
+    intersect_scene_mode<MODE>(S, ro, rd, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
     if (!on) return;
     V3 nw = mk(0.0f, 0.0f, 0.0f);
     float uvx = 0.0f, uvy = 0.0f, uu = 0.0f, vv = 0.0f;
@@ -99,6 +100,8 @@ template <bool FIRST, int MODE>
 __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V, const BounceArgs A)
 {
     __shared__ uint32_t wave_count[kBlock / 64];
+    __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];
+    const unsigned long long kc0 = PTK_CLOCK();
     const uint32_t seg = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t slot = seg * kBlock + tid;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
     }
 
     Hit h;
-    intersect_scene_mode<MODE>(S, o, d, on, h);
+    intersect_scene_mode<MODE>(S, o, d, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
 
     bool alive = false;
     if (on) {
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
         }
     }
 
+    PTK_STAT(S, 12, PTK_CLOCK() - kc0);
     if (A.bounce + 1 >= PTK_MAX_DEPTH) return;
 
     // In-segment compaction: wave64 ballot + mbcnt prefix, then a scan over the
@@ -331,6 +335,7 @@ struct ptk_ctx {
     int traversal = 2; // PTK_OPT_TRAVERSAL
     int kd_prune = 1;  // PTK_OPT_KD_PRUNE
     int node_cull = 2; // PTK_OPT_NODE_CULL
+    int balance = 2;   // PTK_OPT_BALANCE
     bool deep_kd = false; // some mesh has more than one KD node (the pruned walk only pays off then)
 
     // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
@@ -431,16 +436,19 @@ void make_shade_record(const ptk_triangle& t, float4* s)
 // coefficient is 256 x (fp32 epsilon x condition number) + 4 x the measured inconsistency of
 // transform * inv_transform; matrices that are ill-conditioned, inconsistent or not finite
 // switch the test off for the node (infinite box), which is always correct.
-void make_cull_bounds(const ptk_node_desc& n, const float lo[3], const float hi[3], DNode& d)
+// Returns the condition estimate ||M||_F ||M^-1||_F the margins were built from, or a negative
+// value when the test was switched off.
+double make_cull_bounds(const ptk_node_desc& n, const float lo[3], const float hi[3], DNode& d)
 {
     const float big = 3.402823466e+38f;
-    auto disable = [&]() {
+    auto disable = [&]() -> double {
         for (int a = 0; a < 3; ++a) {
             d.wmin[a] = -big;
             d.wmax[a] = big;
         }
         d.cull_k = 0.0f;
         d.cull_c = 0.0f;
+        return -1.0;
     };
     const float* M = n.transform;      // column-major: M[c*4+r]
     const float* I = n.inv_transform;
@@ -484,6 +492,40 @@ void make_cull_bounds(const ptk_node_desc& n, const float lo[3], const float hi[
     }
     d.cull_k = (float)k;
     d.cull_c = (float)(k * (mag + tres) + 4.0 * tres) + 1e-30f;
+    return cond;
+}
+
+// DCull record of a node (intersect_scene_balanced).  `planar`: the face normal every triangle of
+// the node's mesh shares (local space), or NULL.  The reference rejects a triangle when
+// cosine = dot(normalize(M^-1 d), N) >= 0 (scene.cpp:18-23,158).  In exact arithmetic that cosine
+// is c_w |M^-T N| / |M^-1 d| with c_w = dot(d, fn), fn = normalize(M^-T N), so c_w >= ftau implies
+// cosine >= ftau / cond.  The fp32 chain that produces the reference's cosine is off by less than
+// 1e-6 * cond, and the triangles' own normals differ from N by less than 2e-6 (checked by the
+// caller), so ftau = 1e-5 * cond^2 (at least 1e-4) leaves a factor of ten; above 0.5 the test is
+// switched off.
+DCull make_cull_record(const ptk_node_desc& n, const DNode& d, double cond, const float* planar)
+{
+    DCull c{};
+    for (int a = 0; a < 3; ++a) {
+        c.wmin[a] = d.wmin[a];
+        c.wmax[a] = d.wmax[a];
+    }
+    c.cull_k = d.cull_k;
+    c.cull_c = d.cull_c;
+    c.cls = d.cls;
+    c.ftau = 2.0f;
+    if (planar && cond > 0.0) {
+        const float* I = n.inv_transform; // column-major I[c*4+r]
+        double w[3];
+        for (int r = 0; r < 3; ++r) w[r] = (double)I[r * 4 + 0] * planar[0] + (double)I[r * 4 + 1] * planar[1] + (double)I[r * 4 + 2] * planar[2];
+        const double len = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double tau = std::fmax(1e-4, 1e-5 * cond * cond);
+        if (std::isfinite(len) && len > 1e-30 && tau <= 0.5) {
+            for (int r = 0; r < 3; ++r) c.fn[r] = (float)(w[r] / len);
+            c.ftau = (float)tau;
+        }
+    }
+    return c;
 }
 
 constexpr size_t kMaxStamps = 8192;
@@ -523,9 +565,12 @@ void drop_stamps(ptk_ctx* c)
 
 // Template MODE of the cast kernels (ptk_device.h, intersect_scene_mode) for this context / scene.
 // `primary`: the coherent camera rays of bounce 0.
+constexpr uint32_t kBalanceMinNodes = 2; // PTK_OPT_BALANCE = 2: pooled work lists from this many nodes on
 constexpr uint32_t kCullMinNodes = 16; // PTK_OPT_NODE_CULL = 2: candidate lists from this many nodes on
 int kernel_mode(const ptk_ctx* c, bool primary)
 {
+    if (c->balance == 1 || (c->balance == 2 && c->S.num_nodes >= kBalanceMinNodes))
+        return 8 | ((c->kd_prune && c->deep_kd) ? 2 : 0);
     const bool cull = c->node_cull == 1 || (c->node_cull == 2 && c->S.num_nodes >= kCullMinNodes);
     // PTK_OPT_TRAVERSAL = 2: primary rays walk every node together unless the cull pays off
     const bool lists = c->traversal == 1 || (c->traversal == 2 && (!primary || cull));
@@ -643,6 +688,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     std::vector<float4> tri_hit, tri_shade;
     std::vector<uint32_t> leaf_prim;
     c->kd_infos.resize(sc->num_meshes);
+    std::vector<float> planar((size_t)sc->num_meshes * 4, 0.0f); // per mesh: shared face normal, flag
     bool deep_kd = false;
     for (uint32_t m = 0; m < sc->num_meshes; ++m) {
         const ptk_mesh_desc& md = sc->meshes[m];
@@ -686,6 +732,21 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         }
         std::vector<float4> rec((size_t)md.num_triangles * 4);
         for (uint64_t t = 0; t < md.num_triangles; ++t) make_hit_record(md.triangles[t], &rec[t * 4]);
+        // planar mesh: every triangle::m_face_normal (scene.cpp:93) within 1e-6 of the first one
+        if (md.num_triangles) {
+            const float n0[3] = { rec[0].w, rec[1].x, rec[1].y };
+            bool same = std::isfinite(n0[0]) && std::isfinite(n0[1]) && std::isfinite(n0[2]);
+            for (uint64_t t = 1; t < md.num_triangles && same; ++t) {
+                const float nt[3] = { rec[t * 4].w, rec[t * 4 + 1].x, rec[t * 4 + 1].y };
+                for (int a = 0; a < 3; ++a) same = same && std::fabs(nt[a] - n0[a]) <= 1e-6f; // false on NaN
+            }
+            if (same) {
+                planar[m * 4 + 0] = n0[0];
+                planar[m * 4 + 1] = n0[1];
+                planar[m * 4 + 2] = n0[2];
+                planar[m * 4 + 3] = 1.0f;
+            }
+        }
         const size_t h0 = tri_hit.size();
         tri_hit.resize(h0 + prims.size() * 4);
         for (size_t k = 0; k < prims.size(); ++k) std::memcpy(&tri_hit[h0 + k * 4], &rec[(size_t)prims[k] * 4], 64);
@@ -696,6 +757,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     }
 
     std::vector<DNode> nodes(sc->num_nodes);
+    std::vector<DCull> culls(sc->num_nodes);
     for (uint32_t i = 0; i < sc->num_nodes; ++i) {
         const ptk_node_desc& n = sc->nodes[i];
         DNode& d = nodes[i];
@@ -712,11 +774,15 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         const float unit_lo[3] = { -1.0f, -1.0f, -1.0f }, unit_hi[3] = { 1.0f, 1.0f, 1.0f };
         if (n.shape_kind == PTK_SHAPE_MESH) {
             const ptk_kd_info& ki = c->kd_infos[n.mesh];
-            make_cull_bounds(n, ki.bmin, ki.bmax, d);
-            d.cls = ki.num_nodes > 1 ? kClassTree : (ki.num_leaf_prims <= kSmallLeafMax ? kClassSmallLeaf : kClassLeaf);
+            const double cond = make_cull_bounds(n, ki.bmin, ki.bmax, d);
+            d.cls = (ki.num_nodes > 1 || ki.num_leaf_prims > kLeafItemMax)
+                        ? kClassTree
+                        : (ki.num_leaf_prims <= kSmallLeafMax ? kClassSmallLeaf : kClassLeaf);
+            culls[i] = make_cull_record(n, d, cond, planar[n.mesh * 4 + 3] != 0.0f ? &planar[n.mesh * 4] : nullptr);
         } else {
-            make_cull_bounds(n, unit_lo, unit_hi, d);
+            const double cond = make_cull_bounds(n, unit_lo, unit_hi, d);
             d.cls = kClassSphere;
+            culls[i] = make_cull_record(n, d, cond, nullptr);
         }
     }
     std::vector<DSampler> samplers(sc->num_samplers);
@@ -738,6 +804,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
 
     DScene S{};
     if (int r = upload(c, nodes, &S.nodes)) return r;
+    if (int r = upload(c, culls, &S.cull)) return r;
     if (int r = upload(c, meshes, &S.meshes)) return r;
     if (int r = upload(c, kd, &S.kd)) return r;
     if (int r = upload(c, tri_hit, &S.tri_hit)) return r;
@@ -755,6 +822,15 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     S.cam_x = sc->camera.position[0];
     S.cam_y = sc->camera.position[1];
     S.cam_z = sc->camera.position[2];
+#ifdef PTK_STATS
+    {
+        void* sp = nullptr;
+        PTK_HIP(c, hipMalloc(&sp, 16 * sizeof(unsigned long long)));
+        PTK_HIP(c, hipMemset(sp, 0, 16 * sizeof(unsigned long long)));
+        c->allocs.push_back(sp);
+        S.stats = static_cast<unsigned long long*>(sp);
+    }
+#endif
     c->S = S;
     c->num_meshes = sc->num_meshes;
     c->num_samplers = sc->num_samplers;
@@ -808,7 +884,9 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
         case 2: PTK_BATCH(2); break;
         case 3: PTK_BATCH(3); break;
         case 5: PTK_BATCH(5); break;
-        default: PTK_BATCH(7); break;
+        case 7: PTK_BATCH(7); break;
+        case 8: PTK_BATCH(8); break;
+        default: PTK_BATCH(10); break;
         }
 #undef PTK_BATCH
     }
@@ -947,7 +1025,9 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
                 case 2: PTK_BOUNCE(true, 2); break;
                 case 3: PTK_BOUNCE(true, 3); break;
                 case 5: PTK_BOUNCE(true, 5); break;
-                default: PTK_BOUNCE(true, 7); break;
+                case 7: PTK_BOUNCE(true, 7); break;
+                case 8: PTK_BOUNCE(true, 8); break;
+                default: PTK_BOUNCE(true, 10); break;
                 }
             }
             for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) {
@@ -959,7 +1039,9 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
                 case 2: PTK_BOUNCE(false, 2); break;
                 case 3: PTK_BOUNCE(false, 3); break;
                 case 5: PTK_BOUNCE(false, 5); break;
-                default: PTK_BOUNCE(false, 7); break;
+                case 7: PTK_BOUNCE(false, 7); break;
+                case 8: PTK_BOUNCE(false, 8); break;
+                default: PTK_BOUNCE(false, 10); break;
                 }
             }
 #undef PTK_BOUNCE
@@ -1056,6 +1138,10 @@ int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
         c->node_cull = value;
         return PTK_OK;
     }
+    if (option == PTK_OPT_BALANCE && value >= 0 && value <= 2) {
+        c->balance = value;
+        return PTK_OK;
+    }
     if (option == PTK_OPT_KD_PRUNE && (value == 0 || value == 1)) {
         c->kd_prune = value;
         return PTK_OK;
@@ -1138,6 +1224,19 @@ int ptk_dev_upload(ptk_ctx* c, void* dst, const void* src, uint64_t bytes)
     PTK_HIP(c, hipStreamSynchronize(c->stream));
     return PTK_OK;
 }
+
+#ifdef PTK_STATS
+/* experiment builds only (-DPTK_STATS): reads and clears the work counters */
+int ptk_debug_stats(ptk_ctx* c, unsigned long long* out16)
+{
+    if (!c || !out16 || !c->has_scene) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    PTK_HIP(c, hipStreamSynchronize(c->stream));
+    PTK_HIP(c, hipMemcpy(out16, c->S.stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    PTK_HIP(c, hipMemset(c->S.stats, 0, 16 * sizeof(unsigned long long)));
+    return PTK_OK;
+}
+#endif
 
 int ptk_reset_counters(ptk_ctx* c)
 {

@@ -34,6 +34,17 @@ struct alignas(16) DNode {
     uint32_t cls;
     uint32_t pad[1];
 };
+// Compact per-node record of the balanced traversal's cull loop (intersect_scene_balanced): the
+// world box and margins of DNode, plus the common face normal of a planar mesh in world space
+// (fn, unit length; zero if the node has none) and the cosine from which a ray direction is
+// certain to face every triangle of the node from behind (ftau; 2 = never).
+struct alignas(16) DCull {
+    float wmin[3], cull_k;
+    float wmax[3], cull_c;
+    float fn[3], ftau;
+    uint32_t cls, pad[3];
+};
+static_assert(sizeof(DCull) == 64, "DCull must be 64 B");
 enum { kClassSphere = 0, kClassSmallLeaf = 1, kClassLeaf = 2, kClassTree = 3, kNumClasses = 4 };
 constexpr uint32_t kSmallLeafMax = 4u; // a one-leaf mesh with at most this many triangles (plane.obj: 2)
 static_assert(sizeof(DNode) == 256, "DNode must be 256 B");
@@ -88,6 +99,7 @@ struct DTexture {
 
 struct DScene {
     const DNode* nodes;
+    const DCull* cull;
     const DMesh* meshes;
     const DKdNode* kd;
     const float4* tri_hit;     // 4 float4 per leaf-ordered primitive
@@ -100,7 +112,17 @@ struct DScene {
     float bg_r, bg_g, bg_b;
     uint32_t bg_texture, bg_mode;
     float cam_x, cam_y, cam_z;
+#ifdef PTK_STATS
+    unsigned long long* stats; // experiment builds only: work counters of the balanced traversal
+#endif
 };
+#ifdef PTK_STATS
+#define PTK_STAT(S, k, v) do { if (lane_id() == 0u) atomicAdd((S).stats + (k), (unsigned long long)(v)); } while (0)
+#define PTK_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
+#else
+#define PTK_STAT(S, k, v) do { } while (0)
+#define PTK_CLOCK() 0ull
+#endif
 
 // abstract_pathtracer.cpp:20-25
 struct DView {
@@ -177,15 +199,11 @@ struct Hit {
     V3 pw;      // world position, scene.cpp:375
 };
 
-// scene.cpp:142-186 mesh::intersect_triangle up to the hit decision, plus the
-// distance bookkeeping of intersect_internal (scene.cpp:196-202).  Returns true
-// and updates (best_d, best_slot, bar, p) when this triangle is hit and strictly closer,
-// or exactly as close but earlier in the reference's visiting order (`slot` = position in
-// the leaf-ordered primitive list = DFS order).  Walked in the reference's own order the
-// slot only ever grows, so the second clause never fires and this is the strict `<` of
-// scene.cpp:198; it is what makes any other visiting order return the same triangle.
-__device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o,
-                                         V3 d, int slot, float& best_d, int& best_slot, V3& bar_out, V3& p_out)
+// scene.cpp:142-186 mesh::intersect_triangle up to the hit decision, and the squared
+// distance intersect_internal ranks hits by (scene.cpp:196).  Returns true when the
+// triangle is hit; bar = (u,v,w) of triangle::baricentric, p = the hit position.
+__device__ __forceinline__ bool tri_eval(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o,
+                                         V3 d, float& dd_out, V3& bar_out, V3& p_out)
 {
     const V3 v0 = mk(q0.x, q0.y, q0.z);
     const V3 N = mk(q0.w, q1.x, q1.y);
@@ -206,14 +224,34 @@ __device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const
     const float u = 1.0f - v - w;
     if (u >= 0 && v >= 0 && w >= 0) {
         const V3 dv = o - projection;
-        const float dd = dot(dv, dv);
-        if (dd < best_d || (dd == best_d && slot < best_slot)) {
-            best_d = dd;
-            best_slot = slot;
-            bar_out = mk(u, v, w);
-            p_out = projection;
-            return true;
-        }
+        dd_out = dot(dv, dv);
+        bar_out = mk(u, v, w);
+        p_out = projection;
+        return true;
+    }
+    return false;
+}
+
+// tri_eval plus the bookkeeping of intersect_internal (scene.cpp:196-202).  Returns true
+// and updates (best_d, best_slot, bar, p) when this triangle is hit and strictly closer,
+// or exactly as close but earlier in the reference's visiting order (`slot` = position in
+// the leaf-ordered primitive list = DFS order).  Walked in the reference's own order the
+// slot only ever grows, so the second clause never fires and this is the strict `<` of
+// scene.cpp:198; it is what makes any other visiting order return the same triangle.
+// best_slot starts at -1 (no hit yet), so a distance equal to the initial FLT_MAX is
+// rejected as the reference's strict compare rejects it.
+__device__ __forceinline__ bool tri_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o,
+                                         V3 d, int slot, float& best_d, int& best_slot, V3& bar_out, V3& p_out)
+{
+    float dd;
+    V3 bar, p;
+    if (!tri_eval(q0, q1, q2, q3, o, d, dd, bar, p)) return false;
+    if (dd < best_d || (dd == best_d && slot < best_slot)) {
+        best_d = dd;
+        best_slot = slot;
+        bar_out = bar;
+        p_out = p;
+        return true;
     }
     return false;
 }
@@ -398,7 +436,7 @@ __device__ __forceinline__ bool mesh_traverse_lane(const DScene& S, const DMesh 
                                                    bool entered_root, int& prim_out, V3& bar_out, V3& p_out)
 {
     float best_d = 3.402823466e+38f;
-    int best_slot = 0x7FFFFFFF;
+    int best_slot = -1;
     bool found = false;
     const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
     if (PRUNE) {
@@ -429,7 +467,7 @@ __device__ __forceinline__ bool mesh_intersect(const DScene& S, const DMesh mesh
         // Every lane walks the same triangles, so the records come in through
         // wave-uniform (scalar) loads and only the box test is per lane.
         float best_d = 3.402823466e+38f;
-        int best_slot = 0x7FFFFFFF;
+        int best_slot = -1;
         bool found = false;
         const DKdNode* __restrict__ kn = S.kd + mesh.kd_base;
         const bool inside = lane_on && box_intersect(kn->cmin[0], kn->cmin[1], kn->cmin[2], kn->cmax[0], kn->cmax[1],
@@ -626,7 +664,7 @@ __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, 
                 const bool inside = work && box_intersect(kn->cmin[0], kn->cmin[1], kn->cmin[2], kn->cmax[0],
                                                           kn->cmax[1], kn->cmax[2], lo, ld);
                 float best_d = 3.402823466e+38f;
-                int best_slot = 0x7FFFFFFF;
+                int best_slot = -1;
                 bool found = false;
                 V3 p = mk(0.0f, 0.0f, 0.0f), a = mk(0.0f, 0.0f, 0.0f);
                 const uint32_t count = inside ? (kn->b_axis & kKdCountMask) : 0u;
@@ -727,12 +765,364 @@ __device__ __forceinline__ void intersect_scene_nodelist(const DScene& S, V3 o, 
     }
 }
 
-// MODE bit 0: per-lane lists instead of the all-lanes-every-node loop (PTK_OPT_TRAVERSAL), bit 1: pruned KD
-// walk (PTK_OPT_KD_PRUNE), bit 2 (with bit 0): candidate lists after the conservative cull (PTK_OPT_NODE_CULL).
-template <int MODE>
-__device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
+// ---- traversal mode 2: wave-balanced work lists ----------------------------------
+// Per-lane lists still leave most of a wave idle: the wave runs as many candidate steps as
+// its busiest lane needs, and a lane that tests the twelve triangles of a cube keeps the
+// other 63 waiting.  Here the work of a wave's 64 rays is pooled in LDS and dealt out evenly,
+// as a three-stage pipeline inside the wave:
+//   1. cull loop (wave-uniform over the compact DCull table): every (ray, node) pair that
+//      survives the conservative tests is appended to a ring with ballot + mbcnt, in node order;
+//   2. whenever 64 pairs are queued (or the nodes are exhausted), lane i takes pair i: it
+//      fetches that ray from its owner lane (ds_bpermute) and runs the reference's arithmetic
+//      for the node: ray -> local, then sphere / KD walk (committed at once) or the root box
+//      test of a one-leaf mesh, whose survivors go to a second ring with their local ray;
+//   3. whenever 64 such candidates are stored, their triangles are dealt to the lanes two at
+//      a time (packed fp32: the two tests run in the two halves of v_pk_* operations, which
+//      are element-wise IEEE, so each half replays the scalar expression tree), grouped by
+//      triangle count so that no lane gets a padding item; then lane i finishes candidate i
+//      (hit -> world).
+// Results are combined with 64-bit LDS atomic minima on the keys the reference's strict `<`
+// loops imply: (squared local distance, leaf slot) inside a mesh (scene.cpp:196-202), (squared
+// world distance, node index) across nodes (scene.cpp:383-391).  Distances are non-negative
+// floats, so their bit patterns order like the values; a key's low word makes it unique, so
+// exactly one lane finds its own key after the minimum and writes the payload.  Any dealing
+// order gives the same winner.  All cross-lane steps sit in wave-uniform control flow
+// (conditions come from ballots).
+constexpr unsigned long long kKeyNone = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t kLeafItemMax = 4096u; // larger one-leaf meshes are walked per lane (class kClassTree)
+
+struct alignas(16) WaveLds {
+    unsigned long long ray_key[64];  // best (d0 bits, node) per ray
+    unsigned long long cand_key[64]; // best (dd bits, leaf slot) per candidate of the window being finished
+    float ray_pay[7][64];            // prim, a0..a2, pw of the ray's best hit
+    float cand_pay[6][64];           // bar, p of the candidate's best triangle
+    uint32_t queue[128];             // ring of (node << 6 | owner lane)
+    float st_ray[6][128];            // ring of box-pierced one-leaf candidates: local ray,
+    uint32_t st_first[128];          //   first leaf slot,
+    uint32_t st_count[128];          //   triangle count,
+    uint32_t st_item[128];           //   (node << 6 | owner lane)
+    uint32_t compact[64];            // window positions of the candidates in the current count group
+};
+
+__device__ __forceinline__ uint32_t lane_id()
 {
-    if ((MODE & 5) == 5) intersect_scene_lanelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// value of `v` in lane `src` (every lane must be active)
+__device__ __forceinline__ float lane_get(float v, uint32_t src)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ V3 lane_get(V3 v, uint32_t src)
+{
+    return mk(lane_get(v.x, src), lane_get(v.y, src), lane_get(v.z, src));
+}
+// orders this wave's LDS traffic around a cross-lane hand-over (LDS is in-order per wave:
+// this only stops the compiler from moving accesses across it)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Two triangles per lane: tri_eval on both halves of packed fp32 operations.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct V3p {
+    f2 x, y, z;
+};
+__device__ __forceinline__ V3p splat(V3 a) { return V3p{ f2{ a.x, a.x }, f2{ a.y, a.y }, f2{ a.z, a.z } }; }
+__device__ __forceinline__ V3p operator+(V3p a, V3p b) { return V3p{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ V3p operator-(V3p a, V3p b) { return V3p{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+__device__ __forceinline__ V3p operator*(V3p a, f2 s) { return V3p{ a.x * s, a.y * s, a.z * s }; }
+__device__ __forceinline__ f2 dot(V3p a, V3p b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// tri_eval (scene.cpp:142-186) for triangles A (records a0..a3) and B (b0..b3) against one ray.
+// Element .x of every packed value is triangle A's, .y triangle B's; the operations and their
+// order are those of tri_eval.  Outputs are meaningful for the triangles whose hit flag is set.
+__device__ __forceinline__ void tri_eval2(const float4 a0, const float4 a1, const float4 a2, const float4 a3,
+                                          const float4 b0, const float4 b1, const float4 b2, const float4 b3, V3 o, V3 d,
+                                          bool on_a, bool on_b, bool& hit_a, bool& hit_b, f2& dd_out, V3p& bar_out,
+                                          V3p& p_out)
+{
+    hit_a = hit_b = false;
+    const V3p v0 = { f2{ a0.x, b0.x }, f2{ a0.y, b0.y }, f2{ a0.z, b0.z } };
+    const V3p N = { f2{ a0.w, b0.w }, f2{ a1.x, b1.x }, f2{ a1.y, b1.y } };
+    const V3p O = splat(o), D = splat(d);
+    const V3p l = O - v0;
+    const f2 distance = dot(l, N);
+    on_a = on_a && !(distance.x < 0);
+    on_b = on_b && !(distance.y < 0);
+    if (!(on_a || on_b)) return;
+    const f2 cosine = dot(D, N);
+    on_a = on_a && !(cosine.x >= 0);
+    on_b = on_b && !(cosine.y >= 0);
+    if (!(on_a || on_b)) return;
+    const f2 tq = f2{ distance.x / -cosine.x, distance.y / -cosine.y };
+    const V3p projection = O + D * tq;
+    const V3p e0 = { f2{ a1.z, b1.z }, f2{ a1.w, b1.w }, f2{ a2.x, b2.x } };
+    const V3p e1 = { f2{ a2.y, b2.y }, f2{ a2.z, b2.z }, f2{ a2.w, b2.w } };
+    const V3p v2 = projection - v0;
+    const f2 d20 = dot(v2, e0);
+    const f2 d21 = dot(v2, e1);
+    const f2 q_d00 = f2{ a3.x, b3.x }, q_d01 = f2{ a3.y, b3.y }, q_d11 = f2{ a3.z, b3.z }, q_inv = f2{ a3.w, b3.w };
+    const f2 v = (q_d11 * d20 - q_d01 * d21) * q_inv;
+    const f2 w = (q_d00 * d21 - q_d01 * d20) * q_inv;
+    const f2 u = f2{ 1.0f, 1.0f } - v - w;
+    hit_a = on_a && u.x >= 0 && v.x >= 0 && w.x >= 0;
+    hit_b = on_b && u.y >= 0 && v.y >= 0 && w.y >= 0;
+    const V3p dv = O - projection;
+    dd_out = dot(dv, dv);
+    bar_out = V3p{ u, v, w };
+    p_out = projection;
+}
+
+template <bool PRUNE>
+__device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best,
+                                                         WaveLds& L)
+{
+    const uint32_t lane = lane_id();
+    best.d0 = 3.402823466e+38f;
+    best.node = -1;
+    best.prim = -1;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    best.pw = mk(0.0f, 0.0f, 0.0f);
+    L.ray_key[lane] = kKeyNone;
+    uint32_t qhead = 0u, qtail = 0u; // (ray, node) ring, wave-uniform
+    uint32_t shead = 0u, stail = 0u; // candidate ring, wave-uniform
+    const unsigned long long ic0 = PTK_CLOCK();
+
+    // scene.cpp:383-391 across nodes: keep the smallest (d0, node)
+    auto commit = [&](bool hit, uint32_t owner, float d0, uint32_t n, int prim, V3 a, V3 pw) {
+        const bool ok = hit && d0 < 3.402823466e+38f; // scene.cpp:386 against the initial best
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d0) << 32) | n;
+        if (ok) atomicMin(&L.ray_key[owner], key);
+        wave_sync();
+        if (ok && L.ray_key[owner] == key) {
+            L.ray_pay[0][owner] = __int_as_float(prim);
+            L.ray_pay[1][owner] = a.x;  L.ray_pay[2][owner] = a.y;  L.ray_pay[3][owner] = a.z;
+            L.ray_pay[4][owner] = pw.x; L.ray_pay[5][owner] = pw.y; L.ray_pay[6][owner] = pw.z;
+        }
+    };
+
+    // stage 3: triangles of the first `cnt` stored candidates, then their hit -> world
+    auto flush = [&](uint32_t cnt) {
+        const unsigned long long tc0 = PTK_CLOCK();
+        PTK_STAT(S, 3, 1);
+        wave_sync();
+        const bool have = lane < cnt;
+        const uint32_t s = (shead + lane) & 127u;
+        const uint32_t my_pairs = have ? ((L.st_count[s] + 1u) >> 1) : 0u;
+        L.cand_key[lane] = kKeyNone;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(my_pairs != 0u);
+        while (todo != 0ull) {
+            // one group = the candidates with the same number of triangle pairs
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)my_pairs, (int)__builtin_ctzll(todo));
+            const uint64_t grp = __builtin_amdgcn_ballot_w64(my_pairs == v);
+            todo &= ~grp;
+            const uint32_t P = (uint32_t)__popcll(grp);
+            if (my_pairs == v) L.compact[mbcnt64(grp)] = lane;
+            wave_sync();
+            // item t = j * P + r: pair j of the group's r-th candidate; lane takes t = lane, lane + 64, ...
+            const uint32_t total = P * v;
+            uint32_t j = (uint32_t)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)P));
+            uint32_t r = lane - j * P;
+            const uint32_t dq = 64u / P, dr = 64u - dq * P;
+            PTK_STAT(S, 4, (total + 63u) / 64u);
+            PTK_STAT(S, 7, total);
+            for (uint32_t t0 = 0u; t0 < total; t0 += 64u) {
+                const bool valid = j < v;
+                const uint32_t c = L.compact[r];
+                const uint32_t cs = (shead + c) & 127u;
+                const V3 co = mk(L.st_ray[0][cs], L.st_ray[1][cs], L.st_ray[2][cs]);
+                const V3 cd = mk(L.st_ray[3][cs], L.st_ray[4][cs], L.st_ray[5][cs]);
+                const uint32_t first_c = L.st_first[cs], count_c = L.st_count[cs];
+                const uint32_t k0 = valid ? 2u * j : 0u;
+                const bool on_b = valid && k0 + 1u < count_c;
+                const uint32_t slot_a = first_c + k0, slot_b = on_b ? slot_a + 1u : slot_a;
+                const float4* ta = S.tri_hit + (size_t)slot_a * 4;
+                const float4* tb = S.tri_hit + (size_t)slot_b * 4;
+                const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3];
+                const float4 b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3];
+                bool hit_a, hit_b;
+                f2 dd2 = f2{ 0.0f, 0.0f };
+                V3p bar2 = splat(mk(0.0f, 0.0f, 0.0f)), p2 = bar2;
+                tri_eval2(a0, a1, a2, a3, b0, b1, b2, b3, co, cd, valid, on_b, hit_a, hit_b, dd2, bar2, p2);
+                hit_a = hit_a && dd2.x < 3.402823466e+38f; // scene.cpp:198 against the initial best
+                hit_b = hit_b && dd2.y < 3.402823466e+38f;
+                const bool take_b = hit_b && (!hit_a || dd2.y < dd2.x); // ties: the lower slot
+                const bool hit = hit_a || hit_b;
+                const float dd = take_b ? dd2.y : dd2.x;
+                const uint32_t slot = take_b ? slot_b : slot_a;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | slot;
+                if (hit) atomicMin(&L.cand_key[c], key);
+                wave_sync();
+                if (hit && L.cand_key[c] == key) {
+                    L.cand_pay[0][c] = take_b ? bar2.x.y : bar2.x.x;
+                    L.cand_pay[1][c] = take_b ? bar2.y.y : bar2.y.x;
+                    L.cand_pay[2][c] = take_b ? bar2.z.y : bar2.z.x;
+                    L.cand_pay[3][c] = take_b ? p2.x.y : p2.x.x;
+                    L.cand_pay[4][c] = take_b ? p2.y.y : p2.y.x;
+                    L.cand_pay[5][c] = take_b ? p2.z.y : p2.z.x;
+                }
+                j += dq;
+                r += dr;
+                if (r >= P) {
+                    r -= P;
+                    ++j;
+                }
+            }
+        }
+        wave_sync();
+        const unsigned long long key = L.cand_key[lane];
+        const bool found = have && key != kKeyNone;
+        if (__builtin_amdgcn_ballot_w64(found) != 0ull) {
+            const uint32_t item = have ? L.st_item[s] : 0u;
+            const uint32_t owner = item & 63u, n = item >> 6;
+            const V3 ro = lane_get(o, owner);
+            const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + n);
+            const V3 bar = mk(L.cand_pay[0][lane], L.cand_pay[1][lane], L.cand_pay[2][lane]);
+            const V3 p = mk(L.cand_pay[3][lane], L.cand_pay[4][lane], L.cand_pay[5][lane]);
+            V3 pw;
+            float d0;
+            lane_hit_to_world(nv, ro, p, pw, d0); // scene.cpp:375,383
+            commit(found, owner, d0, n, (int)(uint32_t)key, bar, pw);
+        }
+        shead += cnt;
+        PTK_STAT(S, 10, PTK_CLOCK() - tc0);
+    };
+
+    // stage 2: lane i < cnt takes the i-th queued (ray, node) pair
+    auto process = [&](uint32_t cnt) {
+        const unsigned long long pc0 = PTK_CLOCK();
+        PTK_STAT(S, 2, 1);
+        wave_sync();
+        const bool have = lane < cnt;
+        const uint32_t item = have ? L.queue[(qhead + lane) & 127u] : 0u;
+        const uint32_t owner = item & 63u, n = item >> 6;
+        const V3 ro = lane_get(o, owner), rd = lane_get(d, owner);
+        const DNode* __restrict__ nd = S.nodes + n;
+        const float4* __restrict__ nv = reinterpret_cast<const float4*>(nd);
+        V3 lo, ld;
+        lane_ray_to_local(nv, ro, rd, lo, ld); // operator*(mat4, ray), scene.cpp:18-23
+        const uint32_t cls = nd->cls;
+        bool hit = false;
+        int prim = -1;
+        V3 p = mk(0.0f, 0.0f, 0.0f), a = mk(0.0f, 0.0f, 0.0f);
+        const bool is_sphere = have && cls == kClassSphere;
+        if (__builtin_amdgcn_ballot_w64(is_sphere) != 0ull) {
+            V3 sp = mk(0.0f, 0.0f, 0.0f);
+            if (is_sphere && sphere_intersect(lo, ld, sp)) {
+                hit = true;
+                p = sp;
+                a = sp;
+            }
+        }
+        const bool is_tree = have && cls == kClassTree;
+        if (__builtin_amdgcn_ballot_w64(is_tree) != 0ull) {
+            const DMesh mesh = S.meshes[is_tree ? nd->mesh : 0u];
+            int tprim = -1;
+            V3 tb = mk(0.0f, 0.0f, 0.0f), tp = mk(0.0f, 0.0f, 0.0f);
+            if (mesh_traverse_lane<PRUNE>(S, mesh, lo, ld, is_tree, false, tprim, tb, tp)) {
+                hit = true;
+                prim = tprim;
+                a = tb;
+                p = tp;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+            V3 pw;
+            float d0;
+            lane_hit_to_world(nv, ro, p, pw, d0); // scene.cpp:375,383
+            commit(hit, owner, d0, n, prim, a, pw);
+        }
+        const bool is_leaf = have && (cls == kClassSmallLeaf || cls == kClassLeaf);
+        if (__builtin_amdgcn_ballot_w64(is_leaf) != 0ull) {
+            // mesh::intersect on a root leaf: box test (scene.cpp:190); the triangles wait in the ring
+            uint32_t count = 0u, first = 0u;
+            if (is_leaf) {
+                const DMesh mesh = S.meshes[nd->mesh];
+                const DKdNode* __restrict__ kn = S.kd + mesh.kd_base;
+                if (box_intersect(kn->cmin[0], kn->cmin[1], kn->cmin[2], kn->cmax[0], kn->cmax[1], kn->cmax[2], lo, ld)) {
+                    count = kn->b_axis & kKdCountMask;
+                    first = mesh.leaf_base + kn->a;
+                }
+            }
+            const uint64_t pm = __builtin_amdgcn_ballot_w64(count != 0u);
+            if (count != 0u) {
+                const uint32_t sl = (stail + mbcnt64(pm)) & 127u;
+                L.st_ray[0][sl] = lo.x; L.st_ray[1][sl] = lo.y; L.st_ray[2][sl] = lo.z;
+                L.st_ray[3][sl] = ld.x; L.st_ray[4][sl] = ld.y; L.st_ray[5][sl] = ld.z;
+                L.st_first[sl] = first;
+                L.st_count[sl] = count;
+                L.st_item[sl] = item;
+            }
+            stail += (uint32_t)__popcll(pm);
+            PTK_STAT(S, 6, __popcll(pm));
+        }
+        qhead += cnt;
+        PTK_STAT(S, 9, PTK_CLOCK() - pc0);
+    };
+
+    // stage 1: conservative cull.  A node is dropped only if the reference cannot report a hit
+    // on it: the ray misses the node's padded world box (see intersect_scene_lanelist), or the
+    // node is a planar one-sided mesh that the ray direction faces from behind (every triangle
+    // then fails `cosine >= 0`, scene.cpp:158; DCull::fn / ftau, make_cull_record in ptk.hip).
+    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const float o1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
+    uint32_t n = 0u;
+    for (;;) {
+        while (n < S.num_nodes && qtail - qhead < 64u) {
+            const DCull* __restrict__ cu = S.cull + n;
+            const float m = cu->cull_k * o1 + cu->cull_c;
+            const float ax = ((cu->wmin[0] - m) - o.x) * inv.x, bx = ((cu->wmax[0] + m) - o.x) * inv.x;
+            const float ay = ((cu->wmin[1] - m) - o.y) * inv.y, by = ((cu->wmax[1] + m) - o.y) * inv.y;
+            const float az = ((cu->wmin[2] - m) - o.z) * inv.z, bz = ((cu->wmax[2] + m) - o.z) * inv.z;
+            const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)); // false on NaN = keep
+            const bool facing_away = d.x * cu->fn[0] + d.y * cu->fn[1] + d.z * cu->fn[2] >= cu->ftau;
+            const bool keep = lane_on && !(missed || t_out < 0.0f || facing_away);
+            const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) L.queue[(qtail + mbcnt64(km)) & 127u] = (n << 6) | lane;
+            qtail += (uint32_t)__popcll(km);
+            ++n;
+        }
+        const uint32_t qn = qtail - qhead;
+        if (qn != 0u) process(qn < 64u ? qn : 64u);
+        const bool drained = n >= S.num_nodes && qtail == qhead;
+        const uint32_t sn = stail - shead;
+        if (sn >= 64u || (drained && sn != 0u)) flush(sn < 64u ? sn : 64u);
+        if (drained && stail == shead) break;
+    }
+    PTK_STAT(S, 0, 1);
+    PTK_STAT(S, 1, qtail);
+    PTK_STAT(S, 11, PTK_CLOCK() - ic0);
+
+    wave_sync();
+    const unsigned long long key = L.ray_key[lane];
+    if (key != kKeyNone) {
+        best.d0 = __uint_as_float((uint32_t)(key >> 32));
+        best.node = (int)(uint32_t)key;
+        best.prim = __float_as_int(L.ray_pay[0][lane]);
+        best.a0 = L.ray_pay[1][lane];
+        best.a1 = L.ray_pay[2][lane];
+        best.a2 = L.ray_pay[3][lane];
+        best.pw = mk(L.ray_pay[4][lane], L.ray_pay[5][lane], L.ray_pay[6][lane]);
+    }
+}
+
+// MODE bit 0: per-lane lists instead of the all-lanes-every-node loop (PTK_OPT_TRAVERSAL), bit 1: pruned KD
+// walk (PTK_OPT_KD_PRUNE), bit 2 (with bit 0): candidate lists after the conservative cull (PTK_OPT_NODE_CULL),
+// bit 3: wave-balanced work lists (PTK_OPT_BALANCE; needs the wave's WaveLds).
+template <int MODE>
+__device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best, WaveLds* L)
+{
+    if (MODE & 8) intersect_scene_balanced<(MODE & 2) != 0>(S, o, d, lane_on, best, *L);
+    else if ((MODE & 5) == 5) intersect_scene_lanelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
     else if (MODE & 1) intersect_scene_nodelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
     else intersect_scene<(MODE & 2) != 0>(S, o, d, lane_on, best);
 }

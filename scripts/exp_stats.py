@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Work counters of the balanced traversal (experiment build: hipcc ... -DPTK_STATS -o scripts/libptk_stats.so).
+Usage: PTK_LIB=scripts/libptk_stats.so python3 scripts/exp_stats.py [workload] [w] [spp]"""
+import ctypes as C
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from pathtracing_amd import Context, _abi  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "room"
+w = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+spp = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+scene = bench.load_workload(wl, 1_000_000)
+ctx = Context(0)
+ctx.set_option(4, 1)
+ctx.upload(scene)
+ctx.render_begin(w, w, math.pi / 4)
+lib = _abi.load()
+lib.ptk_debug_stats.restype = C.c_int
+lib.ptk_debug_stats.argtypes = [C.c_void_p, C.c_void_p]
+out = (C.c_ulonglong * 16)()
+lib.ptk_debug_stats(ctx._h, out)
+total = torch.zeros(w, w, 3, device="cuda")
+ctx.render_samples_dev(0, 0, spp, total.data_ptr())
+torch.cuda.synchronize()
+lib.ptk_debug_stats(ctx._h, out)
+v = list(out)
+waves = max(1, v[0])
+print(f"waves {v[0]}  candidates/wave {v[1]/waves:.1f}  batches/wave {v[2]/waves:.2f}  tri stages/wave {v[3]/waves:.2f}  "
+      f"tri iterations/wave {v[4]/waves:.2f}  P/stage {v[6]/max(1,v[3]):.1f}  slots/stage {v[7]/max(1,v[3]):.1f}")
+print(f"cycles/wave: kernel(to shade end) {v[12]/waves:.0f}  intersect {v[11]/waves:.0f}  batches {v[9]/waves:.0f} (of which tri stages {v[10]/waves:.0f})  "
+      f"=> cull loop {(v[11]-v[9])/waves:.0f}  batch excl tri {(v[9]-v[10])/waves:.0f}  shade+io {(v[12]-v[11])/waves:.0f}")
+ctx.close()

@@ -690,11 +690,31 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     c->kd_infos.resize(sc->num_meshes);
     std::vector<float> planar((size_t)sc->num_meshes * 4, 0.0f); // per mesh: shared face normal, flag
     bool deep_kd = false;
-    for (uint32_t m = 0; m < sc->num_meshes; ++m) {
+    // One-leaf meshes (plane, cube: the 1.5x rule keeps them whole) are laid out first and on even
+    // leaf slots, so that the pair table below can be indexed by slot / 2.
+    std::vector<std::vector<ptk_kd_node>> built_nodes(sc->num_meshes);
+    std::vector<std::vector<uint32_t>> built_prims(sc->num_meshes);
+    std::vector<uint32_t> order;
+    for (uint32_t m = 0; m < sc->num_meshes; ++m)
+        ptk_kd_build_vectors(sc->meshes[m].triangles, sc->meshes[m].num_triangles, &c->kd_infos[m], built_nodes[m],
+                             built_prims[m]);
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint32_t m = 0; m < sc->num_meshes; ++m)
+            if ((built_nodes[m].size() > 1) == (pass == 1)) order.push_back(m);
+    size_t one_leaf_slots = 0;
+    for (uint32_t m : order) {
         const ptk_mesh_desc& md = sc->meshes[m];
         std::vector<ptk_kd_node> nodes;
         std::vector<uint32_t> prims;
-        ptk_kd_build_vectors(md.triangles, md.num_triangles, &c->kd_infos[m], nodes, prims);
+        nodes.swap(built_nodes[m]);
+        prims.swap(built_prims[m]);
+        if (nodes.size() <= 1) {
+            if (leaf_prim.size() & 1u) { // pad to an even slot (never referenced by a leaf)
+                leaf_prim.push_back(0u);
+                tri_hit.resize(tri_hit.size() + 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            }
+            one_leaf_slots = leaf_prim.size() + prims.size();
+        }
         if (kd.size() + nodes.size() > 0xFFFFFFF0ull || leaf_prim.size() + prims.size() > 0x7FFFFFF0ull)
             return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: scene exceeds 32-bit table indices");
         DMesh& dm = meshes[m];
@@ -755,6 +775,18 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         tri_shade.resize(s0 + (size_t)md.num_triangles * 4);
         for (uint64_t t = 0; t < md.num_triangles; ++t) make_shade_record(md.triangles[t], &tri_shade[s0 + t * 4]);
     }
+    // Pair table of the one-leaf meshes (intersect_scene_balanced): slots 2k and 2k+1 interleaved
+    // word by word, so one 16-B load yields two packed-fp32 operands.  An odd tail repeats itself.
+    std::vector<float4> tri_pair(((one_leaf_slots + 1) / 2) * 8);
+    for (size_t k = 0; k * 2 < one_leaf_slots; ++k) {
+        const float* A = reinterpret_cast<const float*>(&tri_hit[(2 * k) * 4]);
+        const float* B = (2 * k + 1 < one_leaf_slots) ? reinterpret_cast<const float*>(&tri_hit[(2 * k + 1) * 4]) : A;
+        float* out = reinterpret_cast<float*>(&tri_pair[k * 8]);
+        for (int w = 0; w < 16; ++w) {
+            out[2 * w] = A[w];
+            out[2 * w + 1] = B[w];
+        }
+    }
 
     std::vector<DNode> nodes(sc->num_nodes);
     std::vector<DCull> culls(sc->num_nodes);
@@ -808,6 +840,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     if (int r = upload(c, meshes, &S.meshes)) return r;
     if (int r = upload(c, kd, &S.kd)) return r;
     if (int r = upload(c, tri_hit, &S.tri_hit)) return r;
+    if (int r = upload(c, tri_pair, &S.tri_pair)) return r;
     if (int r = upload(c, leaf_prim, &S.leaf_prim)) return r;
     if (int r = upload(c, tri_shade, &S.tri_shade)) return r;
     if (int r = upload(c, samplers, &S.samplers)) return r;

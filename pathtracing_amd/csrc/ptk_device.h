@@ -103,6 +103,7 @@ struct DScene {
     const DMesh* meshes;
     const DKdNode* kd;
     const float4* tri_hit;     // 4 float4 per leaf-ordered primitive
+    const float4* tri_pair;    // 8 float4 per pair of leaf slots (2k, 2k+1) of the one-leaf meshes, interleaved
     const uint32_t* leaf_prim; // original triangle index per leaf-ordered primitive
     const float4* tri_shade;   // 4 float4 per original triangle
     const DSampler* samplers;
@@ -840,35 +841,35 @@ __device__ __forceinline__ V3p operator-(V3p a, V3p b) { return V3p{ a.x - b.x, 
 __device__ __forceinline__ V3p operator*(V3p a, f2 s) { return V3p{ a.x * s, a.y * s, a.z * s }; }
 __device__ __forceinline__ f2 dot(V3p a, V3p b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// tri_eval (scene.cpp:142-186) for triangles A (records a0..a3) and B (b0..b3) against one ray.
-// Element .x of every packed value is triangle A's, .y triangle B's; the operations and their
-// order are those of tri_eval.  Outputs are meaningful for the triangles whose hit flag is set.
-__device__ __forceinline__ void tri_eval2(const float4 a0, const float4 a1, const float4 a2, const float4 a3,
-                                          const float4 b0, const float4 b1, const float4 b2, const float4 b3, V3 o, V3 d,
+// tri_eval (scene.cpp:142-186) for the triangles A and B of one pair record (DScene::tri_pair)
+// against one ray.  r[m] = { A[2m], B[2m], A[2m+1], B[2m+1] } over the 16 words of a hit record
+// (v0 N e0 e1 d00 d01 d11 inv_den).  Element .x of every packed value is triangle A's, .y
+// triangle B's; the operations and their order are those of tri_eval.  Outputs are meaningful
+// for the triangles whose hit flag is set.
+__device__ __forceinline__ void tri_eval2(const float4 r0, const float4 r1, const float4 r2, const float4 r3,
+                                          const float4 r4, const float4 r5, const float4 r6, const float4 r7, V3 o, V3 d,
                                           bool on_a, bool on_b, bool& hit_a, bool& hit_b, f2& dd_out, V3p& bar_out,
                                           V3p& p_out)
 {
-    hit_a = hit_b = false;
-    const V3p v0 = { f2{ a0.x, b0.x }, f2{ a0.y, b0.y }, f2{ a0.z, b0.z } };
-    const V3p N = { f2{ a0.w, b0.w }, f2{ a1.x, b1.x }, f2{ a1.y, b1.y } };
+    // no early exits: after the cull almost every wave has a lane that needs the whole test
+    const V3p v0 = { f2{ r0.x, r0.y }, f2{ r0.z, r0.w }, f2{ r1.x, r1.y } };
+    const V3p N = { f2{ r1.z, r1.w }, f2{ r2.x, r2.y }, f2{ r2.z, r2.w } };
     const V3p O = splat(o), D = splat(d);
     const V3p l = O - v0;
     const f2 distance = dot(l, N);
     on_a = on_a && !(distance.x < 0);
     on_b = on_b && !(distance.y < 0);
-    if (!(on_a || on_b)) return;
     const f2 cosine = dot(D, N);
     on_a = on_a && !(cosine.x >= 0);
     on_b = on_b && !(cosine.y >= 0);
-    if (!(on_a || on_b)) return;
     const f2 tq = f2{ distance.x / -cosine.x, distance.y / -cosine.y };
     const V3p projection = O + D * tq;
-    const V3p e0 = { f2{ a1.z, b1.z }, f2{ a1.w, b1.w }, f2{ a2.x, b2.x } };
-    const V3p e1 = { f2{ a2.y, b2.y }, f2{ a2.z, b2.z }, f2{ a2.w, b2.w } };
+    const V3p e0 = { f2{ r3.x, r3.y }, f2{ r3.z, r3.w }, f2{ r4.x, r4.y } };
+    const V3p e1 = { f2{ r4.z, r4.w }, f2{ r5.x, r5.y }, f2{ r5.z, r5.w } };
     const V3p v2 = projection - v0;
     const f2 d20 = dot(v2, e0);
     const f2 d21 = dot(v2, e1);
-    const f2 q_d00 = f2{ a3.x, b3.x }, q_d01 = f2{ a3.y, b3.y }, q_d11 = f2{ a3.z, b3.z }, q_inv = f2{ a3.w, b3.w };
+    const f2 q_d00 = f2{ r6.x, r6.y }, q_d01 = f2{ r6.z, r6.w }, q_d11 = f2{ r7.x, r7.y }, q_inv = f2{ r7.z, r7.w };
     const f2 v = (q_d11 * d20 - q_d01 * d21) * q_inv;
     const f2 w = (q_d00 * d21 - q_d01 * d20) * q_inv;
     const f2 u = f2{ 1.0f, 1.0f } - v - w;
@@ -942,15 +943,13 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
                 const uint32_t first_c = L.st_first[cs], count_c = L.st_count[cs];
                 const uint32_t k0 = valid ? 2u * j : 0u;
                 const bool on_b = valid && k0 + 1u < count_c;
-                const uint32_t slot_a = first_c + k0, slot_b = on_b ? slot_a + 1u : slot_a;
-                const float4* ta = S.tri_hit + (size_t)slot_a * 4;
-                const float4* tb = S.tri_hit + (size_t)slot_b * 4;
-                const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3];
-                const float4 b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3];
+                const uint32_t slot_a = first_c + k0, slot_b = slot_a + 1u; // first_c is even (ptk_scene_upload)
+                const float4* tp = S.tri_pair + (size_t)(slot_a >> 1) * 8;
+                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4], r5 = tp[5], r6 = tp[6], r7 = tp[7];
                 bool hit_a, hit_b;
-                f2 dd2 = f2{ 0.0f, 0.0f };
-                V3p bar2 = splat(mk(0.0f, 0.0f, 0.0f)), p2 = bar2;
-                tri_eval2(a0, a1, a2, a3, b0, b1, b2, b3, co, cd, valid, on_b, hit_a, hit_b, dd2, bar2, p2);
+                f2 dd2;
+                V3p bar2, p2;
+                tri_eval2(r0, r1, r2, r3, r4, r5, r6, r7, co, cd, valid, on_b, hit_a, hit_b, dd2, bar2, p2);
                 hit_a = hit_a && dd2.x < 3.402823466e+38f; // scene.cpp:198 against the initial best
                 hit_b = hit_b && dd2.y < 3.402823466e+38f;
                 const bool take_b = hit_b && (!hit_a || dd2.y < dd2.x); // ties: the lower slot

@@ -506,10 +506,9 @@ double make_cull_bounds(const ptk_node_desc& n, const float lo[3], const float h
 DCull make_cull_record(const ptk_node_desc& n, const DNode& d, double cond, const float* planar)
 {
     DCull c{};
-    for (int a = 0; a < 3; ++a) {
-        c.wmin[a] = d.wmin[a];
-        c.wmax[a] = d.wmax[a];
-    }
+    c.bx[0] = d.wmin[0]; c.bx[1] = d.wmax[0];
+    c.by[0] = d.wmin[1]; c.by[1] = d.wmax[1];
+    c.bz[0] = d.wmin[2]; c.bz[1] = d.wmax[2];
     c.cull_k = d.cull_k;
     c.cull_c = d.cull_c;
     c.cls = d.cls;

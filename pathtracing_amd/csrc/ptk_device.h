@@ -39,8 +39,8 @@ struct alignas(16) DNode {
 // (fn, unit length; zero if the node has none) and the cosine from which a ray direction is
 // certain to face every triangle of the node from behind (ftau; 2 = never).
 struct alignas(16) DCull {
-    float wmin[3], cull_k;
-    float wmax[3], cull_c;
+    float bx[2], by[2], bz[2]; // { wmin, wmax } per axis: one packed operand each
+    float cull_k, cull_c;
     float fn[3], ftau;
     uint32_t cls, pad[3];
 };
@@ -1070,21 +1070,35 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
     // on it: the ray misses the node's padded world box (see intersect_scene_lanelist), or the
     // node is a planar one-sided mesh that the ray direction faces from behind (every triangle
     // then fails `cosine >= 0`, scene.cpp:158; DCull::fn / ftau, make_cull_record in ptk.hip).
-    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    // The slab quotients are (b -+ m - o) / d = (b -+ m) * inv - o * inv: one packed add and one packed
+    // fma per axis.  (Explicit fma: this test is ours, not the reference's; its rounding is far inside
+    // the margins.)  The reciprocals are clamped to +-1e30 so that a ray parallel to an axis gives huge
+    // finite quotients of the right sign instead of inf - inf; rays with non-finite or absurdly large
+    // coordinates are not culled at all (`sane`).
+    const V3 inv = mk(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e30f, 1e30f),
+                      __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e30f, 1e30f),
+                      __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e30f, 1e30f));
+    const V3 noi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     const float o1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
+    const bool sane = o1 + (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)) < 1e8f; // false on NaN
     uint32_t n = 0u;
     for (;;) {
         while (n < S.num_nodes && qtail - qhead < 64u) {
-            const DCull* __restrict__ cu = S.cull + n;
-            const float m = cu->cull_k * o1 + cu->cull_c;
-            const float ax = ((cu->wmin[0] - m) - o.x) * inv.x, bx = ((cu->wmax[0] + m) - o.x) * inv.x;
-            const float ay = ((cu->wmin[1] - m) - o.y) * inv.y, by = ((cu->wmax[1] + m) - o.y) * inv.y;
-            const float az = ((cu->wmin[2] - m) - o.z) * inv.z, bz = ((cu->wmax[2] + m) - o.z) * inv.z;
-            const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-            const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            // constant address space: the record comes in through scalar loads even though the
+            // kernel writes other global memory (ray state) in between
+            const __attribute__((address_space(4))) DCull* cu =
+                (const __attribute__((address_space(4))) DCull*)(S.cull + n);
+            const float m = __builtin_fmaf(cu->cull_k, o1, cu->cull_c);
+            const f2 pm = f2{ -m, m };
+            const f2 tx = __builtin_elementwise_fma(f2{ cu->bx[0], cu->bx[1] } + pm, f2{ inv.x, inv.x }, f2{ noi.x, noi.x });
+            const f2 ty = __builtin_elementwise_fma(f2{ cu->by[0], cu->by[1] } + pm, f2{ inv.y, inv.y }, f2{ noi.y, noi.y });
+            const f2 tz = __builtin_elementwise_fma(f2{ cu->bz[0], cu->bz[1] } + pm, f2{ inv.z, inv.z }, f2{ noi.z, noi.z });
+            const float t_in = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+            const float t_out = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
             const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)); // false on NaN = keep
-            const bool facing_away = d.x * cu->fn[0] + d.y * cu->fn[1] + d.z * cu->fn[2] >= cu->ftau;
-            const bool keep = lane_on && !(missed || t_out < 0.0f || facing_away);
+            const bool facing_away =
+                __builtin_fmaf(d.x, cu->fn[0], __builtin_fmaf(d.y, cu->fn[1], d.z * cu->fn[2])) >= cu->ftau;
+            const bool keep = lane_on && !(sane && (missed || t_out < 0.0f || facing_away));
             const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
             if (keep) L.queue[(qtail + mbcnt64(km)) & 127u] = (n << 6) | lane;
             qtail += (uint32_t)__popcll(km);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch(const DScene S, uint
     float uvx = 0.0f, uvy = 0.0f, uu = 0.0f, vv = 0.0f;
     int prim_id = -1;
     const bool hit = h.node >= 0;
-    if (hit) hit_attributes(S, h, nw, uvx, uvy, prim_id, uu, vv);
+    if (hit) hit_attributes<true>(S, h, nw, uvx, uvy, prim_id, uu, vv);
     if (node) node[i] = h.node;
     if (prim) prim[i] = prim_id;
     if (t) t[i] = hit ? sqrtf(h.d0) : 0.0f;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
             V3 n;
             float uvx, uvy, uu, vv;
             int prim_id;
-            hit_attributes(S, h, n, uvx, uvy, prim_id, uu, vv);
+            hit_attributes<false>(S, h, n, uvx, uvy, prim_id, uu, vv);
             const DNode* __restrict__ nd = S.nodes + h.node;
             // pathtracer.cpp:34-37
             const V3 albedo = sampler_sample(S, nd->albedo, uvx, uvy);
@@ -802,6 +802,10 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         d.emission = n.emission;
         d.roughness = n.roughness;
         d.metallic = n.metallic;
+        d.uses_uv = (sc->samplers[n.albedo].kind == PTK_SAMPLER_IMAGE || sc->samplers[n.emission].kind == PTK_SAMPLER_IMAGE ||
+                     sc->samplers[n.roughness].kind == PTK_SAMPLER_IMAGE || sc->samplers[n.metallic].kind == PTK_SAMPLER_IMAGE)
+                        ? 1u
+                        : 0u;
         const float unit_lo[3] = { -1.0f, -1.0f, -1.0f }, unit_hi[3] = { 1.0f, 1.0f, 1.0f };
         if (n.shape_kind == PTK_SHAPE_MESH) {
             const ptk_kd_info& ki = c->kd_infos[n.mesh];

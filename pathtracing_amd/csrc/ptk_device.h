@@ -32,7 +32,7 @@ struct alignas(16) DNode {
     // Work class for the per-lane candidate loops: lanes of a wave run in lockstep, so candidates
     // are processed class by class to keep the triangle-loop trip counts alike (kClass*).
     uint32_t cls;
-    uint32_t pad[1];
+    uint32_t uses_uv; // 1 if any of the node's four samplers reads an image (else raycast_result::uv is never looked at)
 };
 // Compact per-node record of the balanced traversal's cull loop (intersect_scene_balanced): the
 // world box and margins of DNode, plus the common face normal of a planar mesh in world space
@@ -1143,6 +1143,9 @@ __device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d
 // Rebuilds raycast_result::normal / uv for the winning hit only (the reference
 // computes them for every candidate, scene.cpp:173-182,433-437; the values for
 // the winner are identical).  n_world: scene.cpp:378.
+// ALWAYS_UV = false: the sphere's lat-long uv (an atan2) is only computed for nodes whose material
+// reads an image; a colour sampler ignores uv (sampler.h:58), so the shaded result is the same.
+template <bool ALWAYS_UV>
 __device__ __forceinline__ void hit_attributes(const DScene& S, const Hit& h, V3& n_world, float& uvx, float& uvy,
                                                int& prim_id, float& u_out, float& v_out)
 {
@@ -1151,7 +1154,8 @@ __device__ __forceinline__ void hit_attributes(const DScene& S, const Hit& h, V3
     if (h.prim < 0) {
         // sphere: scene.cpp:433-437
         nl = normalize(mk(h.a0, h.a1, h.a2));
-        uvx = atan2f(nl.x, nl.z) / 3.14159265358979323846f + 0.5f;
+        uvx = 0.0f;
+        if (ALWAYS_UV || nd->uses_uv != 0u) uvx = atan2f(nl.x, nl.z) / 3.14159265358979323846f + 0.5f;
         uvy = nl.y * 0.5f + 0.5f;
         prim_id = -1;
         u_out = uvx;

@@ -1150,28 +1150,30 @@ __device__ __forceinline__ void hit_attributes(const DScene& S, const Hit& h, V3
                                                int& prim_id, float& u_out, float& v_out)
 {
     const DNode* __restrict__ nd = S.nodes + h.node;
-    V3 nl;
-    if (h.prim < 0) {
-        // sphere: scene.cpp:433-437
-        nl = normalize(mk(h.a0, h.a1, h.a2));
-        uvx = 0.0f;
-        if (ALWAYS_UV || nd->uses_uv != 0u) uvx = atan2f(nl.x, nl.z) / 3.14159265358979323846f + 0.5f;
-        uvy = nl.y * 0.5f + 0.5f;
-        prim_id = -1;
-        u_out = uvx;
-        v_out = uvy;
-    } else {
+    // the vector to normalise is picked per shape first, so a wave with both shapes normalises once
+    V3 nl = mk(h.a0, h.a1, h.a2); // sphere: the local hit position, scene.cpp:433
+    uvx = uvy = 0.0f;
+    prim_id = -1;
+    if (h.prim >= 0) {
         const DMesh mesh = S.meshes[nd->mesh];
         const uint32_t tri = S.leaf_prim[h.prim];
         const float4* s = S.tri_shade + (size_t)(mesh.shade_base + tri) * 4;
         const float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
         const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
-        nl = normalize(n0 * h.a0 + n1 * h.a1 + n2 * h.a2);                // scene.cpp:175-178
+        nl = n0 * h.a0 + n1 * h.a1 + n2 * h.a2;                           // scene.cpp:175-178
         uvx = h.a0 * s2.y + h.a1 * s2.w + h.a2 * s3.y;                    // scene.cpp:179-182
         uvy = h.a0 * s2.z + h.a1 * s3.x + h.a2 * s3.z;
         prim_id = (int)tri;
         u_out = h.a1;
         v_out = h.a2;
+    }
+    nl = normalize(nl);
+    if (h.prim < 0) {
+        // sphere: scene.cpp:434-437
+        if (ALWAYS_UV || nd->uses_uv != 0u) uvx = atan2f(nl.x, nl.z) / 3.14159265358979323846f + 0.5f;
+        uvy = nl.y * 0.5f + 0.5f;
+        u_out = uvx;
+        v_out = uvy;
     }
     n_world = normalize(mat_point(nd->nrm, nl, 0.0f));
 }
@@ -1263,9 +1265,10 @@ __device__ __forceinline__ void rng_pair(uint64_t seed, uint32_t pixel, uint64_t
 // rng::hemisphere, rng.cpp:12-36
 __device__ __forceinline__ V3 hemisphere_dir(V3 n, float u1, float u2)
 {
-    V3 t;
-    if (fabsf(n.x) > fabsf(n.y)) t = normalize(mk(n.z, 0.0f, -n.x));
-    else t = normalize(mk(0.0f, -n.z, n.y));
+    // rng.cpp:16-21: one of two tangents; the operands are selected first so that a wave whose
+    // lanes disagree runs the normalisation once (same operations on the same values either way)
+    const bool xc = fabsf(n.x) > fabsf(n.y);
+    const V3 t = normalize(mk(xc ? n.z : 0.0f, xc ? 0.0f : -n.z, xc ? -n.x : n.y));
     const V3 b = cross(n, t);
     const float z = u1;
     const float r = sqrtf(1.0f - z * z);

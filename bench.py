@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--kd-prune", type=int, default=None, help="PTK_OPT_KD_PRUNE override (0/1), for A/B runs")
     ap.add_argument("--node-cull", type=int, default=None, help="PTK_OPT_NODE_CULL override (0/1/2), for A/B runs")
     ap.add_argument("--balance", type=int, default=None, help="PTK_OPT_BALANCE override (0/1/2), for A/B runs")
+    ap.add_argument("--split", type=int, default=None, help="PTK_OPT_SPLIT override (0/1/2), for A/B runs")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="room")
     ap.add_argument("--triangles", type=int, default=5_000_000, help="synthetic workload: triangle count")
     ap.add_argument("--resolution", type=int, nargs=2, default=None)
@@ -158,6 +159,8 @@ def main():
         ctx.set_option(3, args.node_cull)
     if args.balance is not None:
         ctx.set_option(4, args.balance)
+    if args.split is not None:
+        ctx.set_option(5, args.split)
     ctx.upload(scene)
     ctx.render_begin(W, H, FOV)
     total = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)

@@ -252,7 +252,7 @@ int ptk_reset_counters(ptk_ctx* ctx);
  * tested in the uniform loop and each lane then visits only the nodes whose box it pierced;
  * 2 (default) = 0 for the coherent primary rays of bounce 0 (1 if PTK_OPT_NODE_CULL applies), 1 for
  * later bounces and for ptk_intersect_batch.  No reference counterpart. */
-enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4 };
+enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5 };
 /* PTK_OPT_KD_PRUNE: how a multi-node KD-tree is walked (mesh::intersect_internal,
  * scene.cpp:188-212).  0 = the reference's order, every box-hit node is visited;
  * 1 (default) = near child first (by the sign of the ray direction on the split axis),
@@ -265,7 +265,13 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * PTK_OPT_BALANCE: 1 = the (ray, node) pairs that survive the conservative cull, and the triangles
  * of the one-leaf meshes among them, are pooled per wave in LDS and dealt evenly to its 64 lanes
  * (overrides PTK_OPT_TRAVERSAL / PTK_OPT_NODE_CULL); 0 = off; 2 (default) = on for scenes with at
- * least two nodes.  Winners are chosen by the reference's own keys, so results do not change. */
+ * least two nodes.  Winners are chosen by the reference's own keys, so results do not change.
+ * PTK_OPT_SPLIT: scenes with KD-trees only (and PTK_OPT_KD_PRUNE, PTK_OPT_BALANCE on, at most 64 tree
+ * nodes).  1 / 2 (default) = a bounce runs as two kernels: one casts every ray against the spheres and
+ * one-leaf meshes and parks the rays that may hit a tree; a persistent walker kernel then walks the
+ * trees of the parked rays, refilling lanes whose walk has ended, and shades them.  Ray queues are
+ * appended to with one atomic per wave, so their order varies; every result is a function of the path
+ * id and does not.  0 = the KD walk stays inside the bounce kernel. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's
@@ -277,8 +283,9 @@ enum {
     PTK_KERNEL_BOUNCE_FIRST = 0,    /* k_bounce<true>:  generate + cast + shade, bounce 0 */
     PTK_KERNEL_BOUNCE_NEXT = 1,     /* k_bounce<false>: cast + shade, bounces 1..4        */
     PTK_KERNEL_ACCUMULATE = 2,      /* k_accumulate                                       */
-    PTK_KERNEL_INTERSECT_BATCH = 3, /* k_intersect_batch                                  */
-    PTK_KERNEL_KINDS = 4
+    PTK_KERNEL_INTERSECT_BATCH = 3, /* k_intersect_batch (+ its walker in split mode)     */
+    PTK_KERNEL_WALK = 4,            /* k_walk: KD walks + shading of the parked rays      */
+    PTK_KERNEL_KINDS = 5
 };
 typedef struct ptk_kernel_timing {
     uint64_t launches;

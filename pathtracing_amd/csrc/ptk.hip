@@ -39,47 +39,63 @@ constexpr uint64_t kDefaultMaxPaths = 1ull << 24;
 
 // ------------------------------------------------------------------ kernels
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_intersect_batch(const DScene S, uint64_t n, const float* __restrict__ o,
-                                                            const float* __restrict__ d, int32_t* __restrict__ node,
-                                                            int32_t* __restrict__ prim, float* __restrict__ t,
-                                                            float* __restrict__ u, float* __restrict__ v,
-                                                            float* __restrict__ position, float* __restrict__ normal,
-                                                            float* __restrict__ uv)
+// Outputs of the parity entry (ptk_intersect_batch*): SoA arrays of n, any may be NULL.
+struct BatchIO {
+    uint64_t n;
+    const float* o;
+    const float* d;
+    int32_t* node;
+    int32_t* prim;
+    float* t;
+    float* u;
+    float* v;
+    float* position;
+    float* normal;
+    float* uv;
+};
+
+__device__ __forceinline__ void write_batch_hit(const DScene& S, const BatchIO& B, uint64_t i, const Hit& h)
 {
-    __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool on = i < n;
-    const uint64_t j = on ? i : 0;
-    const V3 ro = mk(o[j], o[n + j], o[2 * n + j]);
-    const V3 rd = mk(d[j], d[n + j], d[2 * n + j]);
-    Hit h;
-    intersect_scene_mode<MODE>(S, ro, rd, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
-    if (!on) return;
+    const uint64_t n = B.n;
     V3 nw = mk(0.0f, 0.0f, 0.0f);
     float uvx = 0.0f, uvy = 0.0f, uu = 0.0f, vv = 0.0f;
     int prim_id = -1;
     const bool hit = h.node >= 0;
     if (hit) hit_attributes<true>(S, h, nw, uvx, uvy, prim_id, uu, vv);
-    if (node) node[i] = h.node;
-    if (prim) prim[i] = prim_id;
-    if (t) t[i] = hit ? sqrtf(h.d0) : 0.0f;
-    if (u) u[i] = uu;
-    if (v) v[i] = vv;
-    if (position) {
-        position[i] = hit ? h.pw.x : 0.0f;
-        position[n + i] = hit ? h.pw.y : 0.0f;
-        position[2 * n + i] = hit ? h.pw.z : 0.0f;
+    if (B.node) B.node[i] = h.node;
+    if (B.prim) B.prim[i] = prim_id;
+    if (B.t) B.t[i] = hit ? sqrtf(h.d0) : 0.0f;
+    if (B.u) B.u[i] = uu;
+    if (B.v) B.v[i] = vv;
+    if (B.position) {
+        B.position[i] = hit ? h.pw.x : 0.0f;
+        B.position[n + i] = hit ? h.pw.y : 0.0f;
+        B.position[2 * n + i] = hit ? h.pw.z : 0.0f;
     }
-    if (normal) {
-        normal[i] = nw.x;
-        normal[n + i] = nw.y;
-        normal[2 * n + i] = nw.z;
+    if (B.normal) {
+        B.normal[i] = nw.x;
+        B.normal[n + i] = nw.y;
+        B.normal[2 * n + i] = nw.z;
     }
-    if (uv) {
-        uv[i] = uvx;
-        uv[n + i] = uvy;
+    if (B.uv) {
+        B.uv[i] = uvx;
+        B.uv[n + i] = uvy;
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_intersect_batch(const DScene S, const BatchIO B)
+{
+    __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];
+    const uint64_t n = B.n;
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool on = i < n;
+    const uint64_t j = on ? i : 0;
+    const V3 ro = mk(B.o[j], B.o[n + j], B.o[2 * n + j]);
+    const V3 rd = mk(B.d[j], B.d[n + j], B.d[2 * n + j]);
+    Hit h;
+    intersect_scene_mode<MODE>(S, ro, rd, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
+    if (on) write_batch_hit(S, B, i, h);
 }
 
 struct BounceArgs {
@@ -95,6 +111,68 @@ struct BounceArgs {
     uint64_t seed;
     uint32_t bounce;
 };
+
+// pathtracer::trace_recursive for one cast (pathtracer.cpp:29-68) in throughput form: updates L, and
+// for a hit before the last bounce turns (o, d, T) into the next ray.  Returns whether the path goes
+// on; a path that ends (miss, depth 5, zero throughput) writes its radiance to sample_L[path].
+__device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, const Hit& h, V3& o, V3& d, V3& T, V3& L,
+                                          uint32_t path)
+{
+    bool alive = false;
+    if (h.node < 0) {
+        // pathtracer.cpp:67: miss -> background
+        L = L + mulv(T, background_sample(S, d));
+    } else {
+        V3 n;
+        float uvx, uvy, uu, vv;
+        int prim_id;
+        hit_attributes<false>(S, h, n, uvx, uvy, prim_id, uu, vv);
+        const DNode* __restrict__ nd = S.nodes + h.node;
+        // pathtracer.cpp:34-37
+        const V3 albedo = sampler_sample(S, nd->albedo, uvx, uvy);
+        const V3 emission = sampler_sample(S, nd->emission, uvx, uvy);
+        const float roughness = sampler_sample(S, nd->roughness, uvx, uvy).x;
+        const float metallic = sampler_sample(S, nd->metallic, uvx, uvy).x;
+        L = L + mulv(T, emission);
+        if (A.bounce + 1 < PTK_MAX_DEPTH) {
+            const uint32_t pl = path / A.samples;
+            const uint32_t sm = path - pl * A.samples;
+            float u1, u2;
+            rng_pair(A.seed, (uint32_t)(A.pixel_begin + pl), A.sample_begin + sm, 1u + A.bounce, u1, u2);
+            // pathtracer.cpp:40-54
+            const V3 hemi = hemisphere_dir(n, u1, u2);
+            const V3 refl = d - n * dot(n, d) * 2.0f;
+            const V3 dir = normalize(mix(refl, hemi, roughness));
+            const float dn = dot(dir, n);
+            const float cos_theta = (0.0f < dn) ? dn : 0.0f;
+            // pathtracer.cpp:60 in throughput form
+            const V3 m = mix(albedo, mk(1.0f, 1.0f, 1.0f), metallic);
+            T = mulv(T, m) * cos_theta * 2.0f;
+            o = h.pw + dir * PTK_EPSILON;
+            d = dir;
+            alive = (T.x != 0.0f) || (T.y != 0.0f) || (T.z != 0.0f);
+        }
+    }
+    if (!alive) {
+        float* __restrict__ sl = A.sample_L;
+        sl[0 * A.cap + path] = L.x;
+        sl[1 * A.cap + path] = L.y;
+        sl[2 * A.cap + path] = L.z;
+    }
+    return alive;
+}
+
+// abstract_pathtracer.cpp:74-83: the jittered camera ray of path `path` of the chunk
+__device__ __forceinline__ void primary_ray(const DScene& S, const DView& V, const BounceArgs& A, uint32_t path, V3& o, V3& d)
+{
+    const uint32_t pl = path / A.samples;
+    const uint32_t sm = path - pl * A.samples;
+    const uint32_t pixel = (uint32_t)(A.pixel_begin + pl);
+    float u1, u2;
+    rng_pair(A.seed, pixel, A.sample_begin + sm, 0u, u1, u2);
+    o = mk(S.cam_x, S.cam_y, S.cam_z);
+    d = primary_dir(V, pixel % V.width, pixel / V.width, u1, u2);
+}
 
 template <bool FIRST, int MODE>
 __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V, const BounceArgs A)
@@ -122,18 +200,9 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
 
     V3 o, d, T, L;
     uint32_t path;
-    uint32_t pixel;
-    uint64_t sample;
     if (FIRST) {
         path = slot;
-        const uint32_t pl = path / A.samples;
-        const uint32_t s = path - pl * A.samples;
-        pixel = (uint32_t)(A.pixel_begin + pl);
-        sample = A.sample_begin + s;
-        float u1, u2;
-        rng_pair(A.seed, pixel, sample, 0u, u1, u2);
-        o = mk(S.cam_x, S.cam_y, S.cam_z);
-        d = primary_dir(V, pixel % V.width, pixel / V.width, u1, u2);
+        primary_ray(S, V, A, path, o, d);
         T = mk(1.0f, 1.0f, 1.0f);
         L = mk(0.0f, 0.0f, 0.0f);
     } else {
@@ -143,56 +212,13 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
         T = mk(st[6 * cap + rs], st[7 * cap + rs], st[8 * cap + rs]);
         L = mk(st[9 * cap + rs], st[10 * cap + rs], st[11 * cap + rs]);
         path = __float_as_uint(st[12 * cap + rs]);
-        const uint32_t pl = path / A.samples;
-        const uint32_t s = path - pl * A.samples;
-        pixel = (uint32_t)(A.pixel_begin + pl);
-        sample = A.sample_begin + s;
     }
 
     Hit h;
     intersect_scene_mode<MODE>(S, o, d, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
 
     bool alive = false;
-    if (on) {
-        if (h.node < 0) {
-            // pathtracer.cpp:67: miss -> background
-            L = L + mulv(T, background_sample(S, d));
-        } else {
-            V3 n;
-            float uvx, uvy, uu, vv;
-            int prim_id;
-            hit_attributes<false>(S, h, n, uvx, uvy, prim_id, uu, vv);
-            const DNode* __restrict__ nd = S.nodes + h.node;
-            // pathtracer.cpp:34-37
-            const V3 albedo = sampler_sample(S, nd->albedo, uvx, uvy);
-            const V3 emission = sampler_sample(S, nd->emission, uvx, uvy);
-            const float roughness = sampler_sample(S, nd->roughness, uvx, uvy).x;
-            const float metallic = sampler_sample(S, nd->metallic, uvx, uvy).x;
-            L = L + mulv(T, emission);
-            if (A.bounce + 1 < PTK_MAX_DEPTH) {
-                float u1, u2;
-                rng_pair(A.seed, pixel, sample, 1u + A.bounce, u1, u2);
-                // pathtracer.cpp:40-54
-                const V3 hemi = hemisphere_dir(n, u1, u2);
-                const V3 refl = d - n * dot(n, d) * 2.0f;
-                const V3 dir = normalize(mix(refl, hemi, roughness));
-                const float dn = dot(dir, n);
-                const float cos_theta = (0.0f < dn) ? dn : 0.0f;
-                // pathtracer.cpp:60 in throughput form
-                const V3 m = mix(albedo, mk(1.0f, 1.0f, 1.0f), metallic);
-                T = mulv(T, m) * cos_theta * 2.0f;
-                o = h.pw + dir * PTK_EPSILON;
-                d = dir;
-                alive = (T.x != 0.0f) || (T.y != 0.0f) || (T.z != 0.0f);
-            }
-        }
-        if (!alive) {
-            float* __restrict__ sl = A.sample_L;
-            sl[0 * cap + path] = L.x;
-            sl[1 * cap + path] = L.y;
-            sl[2 * cap + path] = L.z;
-        }
-    }
+    if (on) alive = shade_ray(S, A, h, o, d, T, L, path);
 
     PTK_STAT(S, 12, PTK_CLOCK() - kc0);
     if (A.bounce + 1 >= PTK_MAX_DEPTH) return;
@@ -219,6 +245,260 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
         st[6 * cap + ws] = T.x;  st[7 * cap + ws] = T.y;  st[8 * cap + ws] = T.z;
         st[9 * cap + ws] = L.x;  st[10 * cap + ws] = L.y; st[11 * cap + ws] = L.z;
         st[12 * cap + ws] = __uint_as_float(path);
+    }
+}
+
+// ---- split mode: scenes with KD-trees -------------------------------------------------------
+// A ray's KD walk takes anything from zero to a few hundred node steps; inside k_bounce the wave
+// waits for its slowest lane.  Split mode (PTK_OPT_SPLIT) cuts a bounce in two kernels:
+//   k_bounce_split  casts every ray against the spheres and one-leaf meshes (balanced traversal) and
+//                   finds the KD-tree nodes it may hit (conservative cull).  Rays without such a node are
+//                   shaded at once; the others are parked: (queue slot, tree bit mask, best hit so far).
+//   k_walk          persistent waves take parked rays from that list, walk their trees and shade them.
+//                   A lane whose walk ends parks its result; when 16 lanes are free the wave fetches new
+//                   rays with one atomic, so the walk loop keeps at least half of the lanes busy until
+//                   the list runs dry (the "replace terminated rays" scheme of persistent traversal).
+// Surviving rays of both kernels are appended to the next bounce's queue with one atomic per wave
+// (ballot + mbcnt prefix); two queues alternate.  Queue order varies from run to run, results do not:
+// every path's random numbers and its sample_L slot are functions of its path id.
+struct SplitBufs {
+    float* q[2];                   // ray queues: kStateFields arrays of `cap` floats each
+    uint32_t* qcount;              // [PTK_MAX_DEPTH + 1] rays entering bounce b
+    uint32_t* pend_count;          // [PTK_MAX_DEPTH] parked rays of bounce b
+    uint32_t* pend_head;           // [PTK_MAX_DEPTH] next parked ray to hand out
+    uint32_t* pend_slot;           // queue slot (render) / ray index (batch) of a parked ray
+    unsigned long long* pend_mask; // its tree nodes: bits over DScene::tree_nodes
+    float* pend_best;              // 9 arrays of `cap`: d0, node, prim, a0..a2, pw of its best hit so far
+    uint64_t cap;
+};
+
+// one atomic per wave; returns this lane's index (meaningful where `want` is set)
+__device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter)
+{
+    const uint64_t m = __builtin_amdgcn_ballot_w64(want);
+    if (m == 0ull) return 0u;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0u;
+    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+    return base + mbcnt64(m);
+}
+
+__device__ __forceinline__ void queue_store(float* __restrict__ q, uint64_t cap, uint32_t ws, V3 o, V3 d, V3 T, V3 L,
+                                            uint32_t path)
+{
+    q[0 * cap + ws] = o.x;  q[1 * cap + ws] = o.y;  q[2 * cap + ws] = o.z;
+    q[3 * cap + ws] = d.x;  q[4 * cap + ws] = d.y;  q[5 * cap + ws] = d.z;
+    q[6 * cap + ws] = T.x;  q[7 * cap + ws] = T.y;  q[8 * cap + ws] = T.z;
+    q[9 * cap + ws] = L.x;  q[10 * cap + ws] = L.y; q[11 * cap + ws] = L.z;
+    q[12 * cap + ws] = __uint_as_float(path);
+}
+
+__device__ __forceinline__ void park_ray(const SplitBufs& Q, uint32_t p, uint32_t slot, unsigned long long mask,
+                                         const Hit& h)
+{
+    const uint64_t cap = Q.cap;
+    Q.pend_slot[p] = slot;
+    Q.pend_mask[p] = mask;
+    float* __restrict__ b = Q.pend_best;
+    b[0 * cap + p] = h.d0;
+    b[1 * cap + p] = __int_as_float(h.node);
+    b[2 * cap + p] = __int_as_float(h.prim);
+    b[3 * cap + p] = h.a0;   b[4 * cap + p] = h.a1;   b[5 * cap + p] = h.a2;
+    b[6 * cap + p] = h.pw.x; b[7 * cap + p] = h.pw.y; b[8 * cap + p] = h.pw.z;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_bounce_split(const DScene S, const DView V, const BounceArgs A, const SplitBufs Q)
+{
+    __shared__ WaveLds wave_lds[kBlock / 64];
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t cnt = FIRST ? A.n_paths : Q.qcount[A.bounce];
+    if (blockIdx.x * kBlock >= cnt) return;
+    const bool on = slot < cnt;
+    const uint64_t cap = A.cap;
+    const float* __restrict__ qin = Q.q[A.bounce & 1u];
+    float* __restrict__ qout = Q.q[(A.bounce + 1u) & 1u];
+
+    V3 o, d, T, L;
+    uint32_t path;
+    if (FIRST) {
+        path = slot;
+        primary_ray(S, V, A, path, o, d);
+        T = mk(1.0f, 1.0f, 1.0f);
+        L = mk(0.0f, 0.0f, 0.0f);
+    } else {
+        const uint32_t rs = on ? slot : 0u;
+        o = mk(qin[0 * cap + rs], qin[1 * cap + rs], qin[2 * cap + rs]);
+        d = mk(qin[3 * cap + rs], qin[4 * cap + rs], qin[5 * cap + rs]);
+        T = mk(qin[6 * cap + rs], qin[7 * cap + rs], qin[8 * cap + rs]);
+        L = mk(qin[9 * cap + rs], qin[10 * cap + rs], qin[11 * cap + rs]);
+        path = __float_as_uint(qin[12 * cap + rs]);
+    }
+
+    Hit h;
+    unsigned long long trees;
+    intersect_scene_balanced<true, true>(S, o, d, on, h, wave_lds[threadIdx.x >> 6], trees);
+
+    const bool parked = on && trees != 0ull;
+    const uint32_t p = wave_alloc(parked, Q.pend_count + A.bounce);
+    if (parked) {
+        park_ray(Q, p, slot, trees, h);
+        // bounce 0 has no input queue: the walker reads the generated ray from queue 0
+        if (FIRST) queue_store(Q.q[0], cap, slot, o, d, T, L, path);
+    }
+    bool alive = false;
+    if (on && !parked) alive = shade_ray(S, A, h, o, d, T, L, path);
+    if (A.bounce + 1 >= PTK_MAX_DEPTH) return;
+    const uint32_t ws = wave_alloc(alive, Q.qcount + A.bounce + 1u);
+    if (alive) queue_store(qout, cap, ws, o, d, T, L, path);
+}
+
+// Parity-entry twin of k_bounce_split: rays from the caller's arrays, hits written out instead of shaded.
+__global__ __launch_bounds__(kBlock) void k_intersect_batch_split(const DScene S, const BatchIO B, const SplitBufs Q)
+{
+    __shared__ WaveLds wave_lds[kBlock / 64];
+    const uint64_t n = B.n;
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool on = i < n;
+    const uint64_t j = on ? i : 0;
+    const V3 ro = mk(B.o[j], B.o[n + j], B.o[2 * n + j]);
+    const V3 rd = mk(B.d[j], B.d[n + j], B.d[2 * n + j]);
+    Hit h;
+    unsigned long long trees;
+    intersect_scene_balanced<true, true>(S, ro, rd, on, h, wave_lds[threadIdx.x >> 6], trees);
+    const bool parked = on && trees != 0ull;
+    const uint32_t p = wave_alloc(parked, Q.pend_count);
+    if (parked) park_ray(Q, p, (uint32_t)i, trees, h);
+    if (on && !parked) write_batch_hit(S, B, i, h);
+}
+
+// The walker.  Lane states: IDLE (no ray), START (has a ray, next tree node not begun), WALK, FIN (walk of
+// one node ended, result not yet folded into the ray's best hit), DONE (all nodes walked, waiting to
+// be shaded).  Every pass of the outer loop makes progress: with fewer than 32 lanes walking there
+// are at least 33 lanes IDLE or DONE after the START/FIN step, so either 16 are IDLE (refill) or 17 are
+// DONE (shade); once the list is dry the walk loop runs the remaining lanes to the end.
+template <bool BATCH>
+__global__ __launch_bounds__(kBlock) void k_walk(const DScene S, const DView V, const BounceArgs A, const SplitBufs Q,
+                                                 const BatchIO B)
+{
+    enum : uint32_t { IDLE = 0u, START = 1u, WALK = 2u, FIN = 3u, DONE = 4u };
+    const uint32_t lane = lane_id();
+    const uint32_t bounce = BATCH ? 0u : A.bounce;
+    const uint32_t pend_total = Q.pend_count[bounce];
+    const uint64_t cap = Q.cap;
+    const float* __restrict__ qin = Q.q[bounce & 1u];
+    float* __restrict__ qout = Q.q[(bounce + 1u) & 1u];
+
+    uint32_t stack_i[kKdStack];
+    float stack_t[kKdStack];
+    KdWalk W;
+    walk_begin(W, S, DMesh{ 0u, 0u, 0u, 0u }, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), false);
+    uint32_t state = IDLE;
+    bool dry = pend_total == 0u; // wave-uniform: the list has been handed out completely
+    uint32_t slot = 0u, node = 0u;
+    unsigned long long trees = 0ull;
+    V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
+    Hit best;
+    best.d0 = 3.402823466e+38f;
+    best.node = -1;
+    best.prim = -1;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    best.pw = mk(0.0f, 0.0f, 0.0f);
+
+    for (;;) {
+        // refill
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(state == IDLE);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (!dry && nidle >= 16u) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(idle);
+            uint32_t base = 0u;
+            if (lane == leader) base = atomicAdd(Q.pend_head + bounce, nidle);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+            const uint32_t mine = base + mbcnt64(idle);
+            if (state == IDLE && mine < pend_total) {
+                slot = Q.pend_slot[mine];
+                trees = Q.pend_mask[mine];
+                const float* __restrict__ pb = Q.pend_best;
+                best.d0 = pb[0 * cap + mine];
+                best.node = __float_as_int(pb[1 * cap + mine]);
+                best.prim = __float_as_int(pb[2 * cap + mine]);
+                best.a0 = pb[3 * cap + mine];
+                best.a1 = pb[4 * cap + mine];
+                best.a2 = pb[5 * cap + mine];
+                best.pw = mk(pb[6 * cap + mine], pb[7 * cap + mine], pb[8 * cap + mine]);
+                if (BATCH) {
+                    o = mk(B.o[slot], B.o[B.n + slot], B.o[2 * B.n + slot]);
+                    d = mk(B.d[slot], B.d[B.n + slot], B.d[2 * B.n + slot]);
+                } else {
+                    o = mk(qin[0 * cap + slot], qin[1 * cap + slot], qin[2 * cap + slot]);
+                    d = mk(qin[3 * cap + slot], qin[4 * cap + slot], qin[5 * cap + slot]);
+                }
+                state = START;
+            }
+            if (base + nidle >= pend_total) dry = true;
+        }
+
+        // FIN -> fold the node's result into the ray's best hit; START -> next tree node or DONE
+        while (__builtin_amdgcn_ballot_w64(state == FIN || state == START) != 0ull) {
+            const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + node);
+            if (state == FIN) {
+                if (W.found) {
+                    V3 pw;
+                    float d0;
+                    lane_hit_to_world(nv, o, W.p, pw, d0); // scene.cpp:375,383
+                    best_update(best, d0, (int)node, W.best_slot, W.bar, pw);
+                }
+                state = START;
+            }
+            if (state == START) {
+                if (trees == 0ull) {
+                    state = DONE;
+                } else {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(trees);
+                    trees &= trees - 1ull;
+                    node = S.tree_nodes[k];
+                    const DNode* __restrict__ nd = S.nodes + node;
+                    V3 lo, ld;
+                    lane_ray_to_local(reinterpret_cast<const float4*>(nd), o, d, lo, ld); // scene.cpp:18-23
+                    walk_begin(W, S, S.meshes[nd->mesh], lo, ld, true);
+                    state = (W.cur != kWalkNone) ? WALK : START; // root missed: straight to the next node
+                }
+            }
+        }
+
+        // walk
+        const uint32_t walk_min = dry ? 1u : 32u;
+        while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == WALK)) >= walk_min) {
+            walk_round(W, S, state == WALK, stack_i, stack_t);
+            if (state == WALK && W.cur == kWalkNone) state = FIN;
+        }
+
+        // shade / write out the rays that are through
+        const uint32_t nbusy = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == WALK || state == FIN));
+        const uint32_t ndone = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == DONE));
+        if (ndone >= 17u || (ndone != 0u && dry && nbusy == 0u)) {
+            const bool fin = state == DONE;
+            if (BATCH) {
+                if (fin) write_batch_hit(S, B, slot, best);
+            } else {
+                V3 T = mk(0.0f, 0.0f, 0.0f), L = T;
+                uint32_t path = 0u;
+                bool alive = false;
+                if (fin) {
+                    T = mk(qin[6 * cap + slot], qin[7 * cap + slot], qin[8 * cap + slot]);
+                    L = mk(qin[9 * cap + slot], qin[10 * cap + slot], qin[11 * cap + slot]);
+                    path = __float_as_uint(qin[12 * cap + slot]);
+                    alive = shade_ray(S, A, best, o, d, T, L, path);
+                }
+                if (bounce + 1u < PTK_MAX_DEPTH) {
+                    const uint32_t ws = wave_alloc(alive, Q.qcount + bounce + 1u);
+                    if (alive) queue_store(qout, cap, ws, o, d, T, L, path);
+                }
+            }
+            if (fin) state = IDLE;
+        }
+        if (dry && __builtin_amdgcn_ballot_w64(state != IDLE) == 0ull) break;
     }
 }
 
@@ -275,6 +555,16 @@ __global__ __launch_bounds__(kBlock) void k_tally(const uint32_t* __restrict__ s
         }
         atomicAdd(&counters[1], tot);
     }
+}
+
+// split mode: rays of a chunk = the queue counts of its bounces
+__global__ void k_tally_split(const uint32_t* __restrict__ qcount, uint32_t n_paths, unsigned long long* __restrict__ counters)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long rays = n_paths;
+    for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) rays += qcount[b];
+    atomicAdd(&counters[0], (unsigned long long)n_paths);
+    atomicAdd(&counters[1], rays);
 }
 
 // abstract_pathtracer.cpp:66,88-90
@@ -336,6 +626,22 @@ struct ptk_ctx {
     int kd_prune = 1;  // PTK_OPT_KD_PRUNE
     int node_cull = 2; // PTK_OPT_NODE_CULL
     int balance = 2;   // PTK_OPT_BALANCE
+    int split = 2;     // PTK_OPT_SPLIT
+    uint32_t num_trees = 0; // nodes of class kClassTree
+
+    // split mode (scenes with KD-trees): second ray queue, parked-ray list, counters
+    float* d_state2 = nullptr;
+    uint32_t* d_split_counters = nullptr; // qcount[PTK_MAX_DEPTH+1] pend_count[PTK_MAX_DEPTH] pend_head[PTK_MAX_DEPTH]
+    uint32_t* d_pend_slot = nullptr;
+    unsigned long long* d_pend_mask = nullptr;
+    float* d_pend_best = nullptr;
+    uint64_t split_cap = 0;
+    // the same for ptk_intersect_batch_dev (sized by the largest batch so far)
+    uint32_t* d_bsplit_counters = nullptr;
+    uint32_t* d_bpend_slot = nullptr;
+    unsigned long long* d_bpend_mask = nullptr;
+    float* d_bpend_best = nullptr;
+    uint64_t bsplit_cap = 0;
     bool deep_kd = false; // some mesh has more than one KD node (the pruned walk only pays off then)
 
     // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
@@ -371,8 +677,34 @@ void free_scene(ptk_ctx* c)
     c->kd_infos.clear();
 }
 
+void free_split(ptk_ctx* c)
+{
+    if (c->d_state2) (void)hipFree(c->d_state2);
+    if (c->d_split_counters) (void)hipFree(c->d_split_counters);
+    if (c->d_pend_slot) (void)hipFree(c->d_pend_slot);
+    if (c->d_pend_mask) (void)hipFree(c->d_pend_mask);
+    if (c->d_pend_best) (void)hipFree(c->d_pend_best);
+    c->d_state2 = c->d_pend_best = nullptr;
+    c->d_split_counters = c->d_pend_slot = nullptr;
+    c->d_pend_mask = nullptr;
+    c->split_cap = 0;
+}
+
+void free_batch_split(ptk_ctx* c)
+{
+    if (c->d_bsplit_counters) (void)hipFree(c->d_bsplit_counters);
+    if (c->d_bpend_slot) (void)hipFree(c->d_bpend_slot);
+    if (c->d_bpend_mask) (void)hipFree(c->d_bpend_mask);
+    if (c->d_bpend_best) (void)hipFree(c->d_bpend_best);
+    c->d_bsplit_counters = c->d_bpend_slot = nullptr;
+    c->d_bpend_mask = nullptr;
+    c->d_bpend_best = nullptr;
+    c->bsplit_cap = 0;
+}
+
 void free_render(ptk_ctx* c)
 {
+    free_split(c);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_sample_L) (void)hipFree(c->d_sample_L);
     if (c->d_seg_count) (void)hipFree(c->d_seg_count);
@@ -576,6 +908,16 @@ int kernel_mode(const ptk_ctx* c, bool primary)
     return (lists ? 1 : 0) | ((c->kd_prune && c->deep_kd) ? 2 : 0) | ((lists && cull) ? 4 : 0);
 }
 
+// PTK_OPT_SPLIT: the two-kernel bounce (k_bounce_split + k_walk) needs the pruned walk and a tree mask of 64 bits
+bool split_mode(const ptk_ctx* c)
+{
+    const bool possible = c->kd_prune && c->deep_kd && c->num_trees >= 1u && c->num_trees <= 64u && c->balance != 0;
+    return possible && c->split != 0;
+}
+
+constexpr uint32_t kWalkBlocks = 1024; // persistent walker grid: 4 resident waves on each of the 1024 SIMDs
+constexpr uint32_t kSplitCounters = 3 * PTK_MAX_DEPTH + 1;
+
 int set_device(ptk_ctx* c)
 {
     PTK_HIP(c, hipSetDevice(c->device));
@@ -617,6 +959,7 @@ void ptk_ctx_destroy(ptk_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     free_render(c);
+    free_batch_split(c);
     drop_stamps(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -820,6 +1163,12 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
             culls[i] = make_cull_record(n, d, cond, nullptr);
         }
     }
+    std::vector<uint32_t> tree_nodes;
+    for (uint32_t i = 0; i < sc->num_nodes; ++i)
+        if (culls[i].cls == kClassTree) {
+            culls[i].tree_slot = (uint32_t)tree_nodes.size();
+            tree_nodes.push_back(i);
+        }
     std::vector<DSampler> samplers(sc->num_samplers);
     for (uint32_t i = 0; i < sc->num_samplers; ++i) {
         const ptk_sampler_desc& s = sc->samplers[i];
@@ -840,6 +1189,8 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     DScene S{};
     if (int r = upload(c, nodes, &S.nodes)) return r;
     if (int r = upload(c, culls, &S.cull)) return r;
+    if (int r = upload(c, tree_nodes, &S.tree_nodes)) return r;
+    S.num_trees = (uint32_t)tree_nodes.size();
     if (int r = upload(c, meshes, &S.meshes)) return r;
     if (int r = upload(c, kd, &S.kd)) return r;
     if (int r = upload(c, tri_hit, &S.tri_hit)) return r;
@@ -873,6 +1224,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     c->num_textures = sc->num_textures;
     c->has_scene = true;
     c->deep_kd = deep_kd;
+    c->num_trees = (uint32_t)tree_nodes.size();
     // camera direction feeds the view basis built by ptk_render_begin
     std::memcpy(c->cam_dir, sc->camera.direction, sizeof(c->cam_dir));
     c->has_view = false;
@@ -910,10 +1262,35 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
     if (n > 0x7FFFFFFFull * kBlock) return fail(c, PTK_ERR_INVALID, "ptk_intersect_batch: batch too large");
     if (int r = set_device(c)) return r;
     const uint32_t blocks = (uint32_t)((n + kBlock - 1) / kBlock);
-    {
+    const BatchIO B{ n, o, d, node, prim, t, u, v, position, normal, uv };
+    const dim3 g(blocks), b(kBlock);
+    if (split_mode(c) && n < 0xFFFFFFFFull) {
+        // two kernels: everything but the KD-trees, then the walker over the parked rays
+        if (n > c->bsplit_cap) {
+            PTK_HIP(c, hipStreamSynchronize(c->stream));
+            free_batch_split(c);
+            PTK_HIP(c, hipMalloc((void**)&c->d_bsplit_counters, kSplitCounters * sizeof(uint32_t)));
+            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_slot, n * sizeof(uint32_t)));
+            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_mask, n * sizeof(unsigned long long)));
+            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_best, n * 9 * sizeof(float)));
+            c->bsplit_cap = n;
+        }
+        PTK_HIP(c, hipMemsetAsync(c->d_bsplit_counters, 0, kSplitCounters * sizeof(uint32_t), c->stream));
+        SplitBufs Q{};
+        Q.qcount = c->d_bsplit_counters;
+        Q.pend_count = c->d_bsplit_counters + PTK_MAX_DEPTH + 1;
+        Q.pend_head = c->d_bsplit_counters + 2 * PTK_MAX_DEPTH + 1;
+        Q.pend_slot = c->d_bpend_slot;
+        Q.pend_mask = c->d_bpend_mask;
+        Q.pend_best = c->d_bpend_best;
+        Q.cap = c->bsplit_cap;
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
-        const dim3 g(blocks), b(kBlock);
-#define PTK_BATCH(M) k_intersect_batch<M><<<g, b, 0, c->stream>>>(c->S, n, o, d, node, prim, t, u, v, position, normal, uv)
+        k_intersect_batch_split<<<g, b, 0, c->stream>>>(c->S, B, Q);
+        const uint32_t wb = blocks < kWalkBlocks ? blocks : kWalkBlocks;
+        k_walk<true><<<dim3(wb), b, 0, c->stream>>>(c->S, c->V, BounceArgs{}, Q, B);
+    } else {
+        LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
+#define PTK_BATCH(M) k_intersect_batch<M><<<g, b, 0, c->stream>>>(c->S, B)
         switch (kernel_mode(c, false)) {
         case 0: PTK_BATCH(0); break;
         case 1: PTK_BATCH(1); break;
@@ -1031,6 +1408,17 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
         return PTK_OK;
     }
     const uint64_t cap = c->cap;
+    const bool split = split_mode(c);
+    if (split && c->split_cap != cap) {
+        PTK_HIP(c, hipStreamSynchronize(c->stream));
+        free_split(c);
+        PTK_HIP(c, hipMalloc((void**)&c->d_state2, cap * kStateFields * sizeof(float)));
+        PTK_HIP(c, hipMalloc((void**)&c->d_split_counters, kSplitCounters * sizeof(uint32_t)));
+        PTK_HIP(c, hipMalloc((void**)&c->d_pend_slot, cap * sizeof(uint32_t)));
+        PTK_HIP(c, hipMalloc((void**)&c->d_pend_mask, cap * sizeof(unsigned long long)));
+        PTK_HIP(c, hipMalloc((void**)&c->d_pend_best, cap * 9 * sizeof(float)));
+        c->split_cap = cap;
+    }
     const uint32_t s_chunk = (uint32_t)((uint64_t)sample_count < cap ? sample_count : cap);
     const uint64_t p_chunk = cap / s_chunk;
     for (uint32_t s0 = 0; s0 < sample_count; s0 += s_chunk) {
@@ -1052,6 +1440,40 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
             A.seed = seed;
             A.bounce = 0;
             const dim3 grid(A.num_segments), block(kBlock);
+            if (split) {
+                PTK_HIP(c, hipMemsetAsync(c->d_split_counters, 0, kSplitCounters * sizeof(uint32_t), c->stream));
+                SplitBufs Q{};
+                Q.q[0] = c->d_state;
+                Q.q[1] = c->d_state2;
+                Q.qcount = c->d_split_counters;
+                Q.pend_count = c->d_split_counters + PTK_MAX_DEPTH + 1;
+                Q.pend_head = c->d_split_counters + 2 * PTK_MAX_DEPTH + 1;
+                Q.pend_slot = c->d_pend_slot;
+                Q.pend_mask = c->d_pend_mask;
+                Q.pend_best = c->d_pend_best;
+                Q.cap = cap;
+                const uint32_t wb = A.num_segments < kWalkBlocks ? A.num_segments : kWalkBlocks;
+                for (uint32_t b = 0; b < PTK_MAX_DEPTH; ++b) {
+                    A.bounce = b;
+                    {
+                        LaunchTimer lt(c, b == 0 ? PTK_KERNEL_BOUNCE_FIRST : PTK_KERNEL_BOUNCE_NEXT);
+                        if (b == 0) k_bounce_split<true><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
+                        else k_bounce_split<false><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
+                    }
+                    LaunchTimer lt(c, PTK_KERNEL_WALK);
+                    k_walk<false><<<dim3(wb), block, 0, c->stream>>>(c->S, c->V, A, Q, BatchIO{});
+                }
+                const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
+                {
+                    LaunchTimer lt(c, PTK_KERNEL_ACCUMULATE);
+                    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, c->d_sample_L, cap,
+                                       (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
+                }
+                hipLaunchKernelGGL(k_tally_split, dim3(1), dim3(64), 0, c->stream, c->d_split_counters, (uint32_t)n_paths,
+                                   c->d_counters);
+                PTK_HIP(c, hipGetLastError());
+                continue;
+            }
 #define PTK_BOUNCE(F, M) k_bounce<F, M><<<grid, block, 0, c->stream>>>(c->S, c->V, A)
             {
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
@@ -1172,6 +1594,10 @@ int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
     }
     if (option == PTK_OPT_NODE_CULL && value >= 0 && value <= 2) {
         c->node_cull = value;
+        return PTK_OK;
+    }
+    if (option == PTK_OPT_SPLIT && value >= 0 && value <= 2) {
+        c->split = value;
         return PTK_OK;
     }
     if (option == PTK_OPT_BALANCE && value >= 0 && value <= 2) {

@@ -42,7 +42,9 @@ struct alignas(16) DCull {
     float bx[2], by[2], bz[2]; // { wmin, wmax } per axis: one packed operand each
     float cull_k, cull_c;
     float fn[3], ftau;
-    uint32_t cls, pad[3];
+    uint32_t cls;
+    uint32_t tree_slot; // class kClassTree: position of the node in DScene::tree_nodes (split mode's pending bit)
+    uint32_t pad[2];
 };
 static_assert(sizeof(DCull) == 64, "DCull must be 64 B");
 enum { kClassSphere = 0, kClassSmallLeaf = 1, kClassLeaf = 2, kClassTree = 3, kNumClasses = 4 };
@@ -108,6 +110,8 @@ struct DScene {
     const float4* tri_shade;   // 4 float4 per original triangle
     const DSampler* samplers;
     const DTexture* textures;
+    const uint32_t* tree_nodes; // nodes of class kClassTree, in node order
+    uint32_t num_trees;
     uint32_t num_nodes;
     uint32_t bg_kind;
     float bg_r, bg_g, bg_b;
@@ -335,99 +339,157 @@ __device__ __forceinline__ bool kd_prune(const float4 y, const float4 z, V3 o, V
 // (slab_decide).  A pending far child is pushed with its distance bound, so a pop can
 // discard it against the best hit found meanwhile without touching memory; a node that
 // is popped gets its six quotients recomputed from its own box.
+//
+// The walk is written as a resumable state (KdWalk) + one "round" (descend to leaves, test
+// them), so that the same code serves the closed per-lane loop (kd_walk_pruned) and the
+// walker kernel, which interleaves rounds with refilling idle lanes (k_walk in ptk.hip).
+constexpr uint32_t kWalkNone = 0xFFFFFFFFu;
+struct KdWalk {
+    const DKdNode* kd;     // the mesh's first node
+    uint32_t leaf_base;    // DMesh::leaf_base
+    V3 o, d, inv;          // local ray, approximate reciprocal direction (pruning only)
+    float oabs;
+    uint32_t neg;          // sign bits of d
+    uint32_t cur, ca, cb, cr; // node being processed (kWalkNone = walk finished) and its header words
+    float cs;
+    float T1, T2, T3, T4, T5, T6; // its six slab quotients
+    int sp;
+    float best_d;
+    int best_slot;
+    bool found;
+    V3 bar, p;
+};
+
+// (re)starts at node `idx`: header words + quotients from its own cut box
+__device__ __forceinline__ void walk_enter(KdWalk& W, uint32_t idx)
+{
+    const float4* __restrict__ q = reinterpret_cast<const float4*>(W.kd + idx);
+    const float4 h = q[0], x = q[1], y = q[2];
+    W.cur = idx;
+    W.ca = __float_as_uint(h.x);
+    W.cb = __float_as_uint(h.y);
+    W.cr = __float_as_uint(h.z);
+    W.cs = h.w;
+    W.T1 = (x.x - W.o.x) / W.d.x;
+    W.T2 = (x.w - W.o.x) / W.d.x;
+    W.T3 = (x.y - W.o.y) / W.d.y;
+    W.T4 = (y.x - W.o.y) / W.d.y;
+    W.T5 = (x.z - W.o.z) / W.d.z;
+    W.T6 = (y.y - W.o.z) / W.d.z;
+}
+
+__device__ __forceinline__ void walk_pop(KdWalk& W, const uint32_t* stack_i, const float* stack_t)
+{
+    W.cur = kWalkNone;
+    while (W.sp > 0) {
+        --W.sp;
+        if (stack_t[W.sp] > W.best_d) continue;
+        walk_enter(W, stack_i[W.sp]);
+        break;
+    }
+}
+
+// Sets the walk up on `mesh` for local ray (o, d) and runs the root's two tests.  With work = false
+// the walk is born finished.
+__device__ __forceinline__ void walk_begin(KdWalk& W, const DScene& S, const DMesh mesh, V3 o, V3 d, bool work)
+{
+    W.kd = S.kd + mesh.kd_base;
+    W.leaf_base = mesh.leaf_base;
+    W.o = o;
+    W.d = d;
+    W.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    W.oabs = 1e-5f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + 1e-30f;
+    W.neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    W.cur = kWalkNone;
+    W.ca = W.cb = W.cr = 0u;
+    W.cs = 0.0f;
+    W.T1 = W.T2 = W.T3 = W.T4 = W.T5 = W.T6 = 0.0f;
+    W.sp = 0;
+    W.best_d = 3.402823466e+38f;
+    W.best_slot = -1;
+    W.found = false;
+    W.bar = W.p = mk(0.0f, 0.0f, 0.0f);
+    if (work) {
+        walk_enter(W, 0u);
+        const float4* __restrict__ q = reinterpret_cast<const float4*>(W.kd);
+        float bound;
+        if (!slab_decide(W.T1, W.T2, W.T3, W.T4, W.T5, W.T6) || kd_prune(q[2], q[3], o, W.inv, W.oabs, W.best_d, bound))
+            W.cur = kWalkNone;
+    }
+}
+
+// One round for the lanes with `active` set: descend until every such lane stands on a leaf (or has
+// run out of nodes), then test those leaves and pop.
+__device__ __forceinline__ void walk_round(KdWalk& W, const DScene& S, bool active, uint32_t* stack_i, float* stack_t)
+{
+    const DKdNode* __restrict__ kd = W.kd;
+    const V3 o = W.o, d = W.d;
+    while (active && W.cur != kWalkNone && (W.cb & kKdCountMask) == 0u) {
+        const uint32_t cur = W.cur, ca = W.ca, cb = W.cb, cr = W.cr;
+        const uint32_t li = cur + 1u;
+        const bool has_l = li < ca; // ca = end of this subtree
+        const bool has_r = cr < ca;
+        const uint32_t ri = has_r ? cr : cur;
+        const float4* __restrict__ ql = reinterpret_cast<const float4*>(kd + (has_l ? li : cur));
+        const float4* __restrict__ qr = reinterpret_cast<const float4*>(kd + ri);
+        const float4 lh = ql[0], ly = ql[2], lz = ql[3];
+        const float4 rh = qr[0], ry = qr[2], rz = qr[3];
+        // the one new plane: both children's boxes are this node's box cut at `cs` on axis k
+        const uint32_t k = cb >> 30;
+        const float ok = k == 0u ? o.x : (k == 1u ? o.y : o.z);
+        const float dk = k == 0u ? d.x : (k == 1u ? d.y : d.z);
+        const float ts = (W.cs - ok) / dk;
+        const float T1 = W.T1, T2 = W.T2, T3 = W.T3, T4 = W.T4, T5 = W.T5, T6 = W.T6;
+        const float L2 = k == 0u ? ts : T2, L4 = k == 1u ? ts : T4, L6 = k == 2u ? ts : T6; // left: max plane moved
+        const float R1 = k == 0u ? ts : T1, R3 = k == 1u ? ts : T3, R5 = k == 2u ? ts : T5; // right: min plane moved
+        float bl, br;
+        const bool el = has_l && slab_decide(T1, L2, T3, L4, T5, L6) && !kd_prune(ly, lz, o, W.inv, W.oabs, W.best_d, bl);
+        const bool er = has_r && slab_decide(R1, T2, R3, T4, R5, T6) && !kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
+        const bool right_first = ((W.neg >> k) & 1u) != 0u;
+        const bool take_r = er && (right_first || !el);
+        if (el && er && W.sp < kKdStack) {
+            stack_i[W.sp] = take_r ? li : ri;
+            stack_t[W.sp] = take_r ? bl : br;
+            ++W.sp;
+        }
+        if (el || er) {
+            W.cur = take_r ? ri : li;
+            W.ca = __float_as_uint(take_r ? rh.x : lh.x);
+            W.cb = __float_as_uint(take_r ? rh.y : lh.y);
+            W.cr = __float_as_uint(take_r ? rh.z : lh.z);
+            W.cs = take_r ? rh.w : lh.w;
+            W.T1 = take_r ? R1 : T1; W.T2 = take_r ? T2 : L2;
+            W.T3 = take_r ? R3 : T3; W.T4 = take_r ? T4 : L4;
+            W.T5 = take_r ? R5 : T5; W.T6 = take_r ? T6 : L6;
+        } else {
+            walk_pop(W, stack_i, stack_t);
+        }
+    }
+    if (active && W.cur != kWalkNone) {
+        leaf_triangles(S, W.leaf_base + W.ca, W.cb & kKdCountMask, o, d, W.best_d, W.best_slot, W.found, W.bar, W.p);
+        walk_pop(W, stack_i, stack_t);
+    }
+}
+
 __device__ __forceinline__ void kd_walk_pruned(const DScene& S, const DMesh mesh, V3 o, V3 d, bool work,
                                                float& best_d, int& best_slot, bool& found, V3& bar_out, V3& p_out)
 {
-    const DKdNode* __restrict__ kd = S.kd + mesh.kd_base;
-    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    const float oabs = 1e-5f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + 1e-30f;
-    const uint32_t neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    const uint32_t none = 0xFFFFFFFFu;
     uint32_t stack_i[kKdStack];
     float stack_t[kKdStack];
-    int sp = 0;
-    // header of the node being processed (it has passed both tests) and its six quotients
-    uint32_t cur = none, ca = 0u, cb = 0u, cr = 0u;
-    float cs = 0.0f;
-    float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f, T4 = 0.0f, T5 = 0.0f, T6 = 0.0f;
-
-    // (re)starts at node `idx`: header words + quotients from its own cut box
-    auto enter = [&](uint32_t idx) {
-        const float4* __restrict__ q = reinterpret_cast<const float4*>(kd + idx);
-        const float4 h = q[0], x = q[1], y = q[2];
-        cur = idx;
-        ca = __float_as_uint(h.x);
-        cb = __float_as_uint(h.y);
-        cr = __float_as_uint(h.z);
-        cs = h.w;
-        T1 = (x.x - o.x) / d.x;
-        T2 = (x.w - o.x) / d.x;
-        T3 = (x.y - o.y) / d.y;
-        T4 = (y.x - o.y) / d.y;
-        T5 = (x.z - o.z) / d.z;
-        T6 = (y.y - o.z) / d.z;
-    };
-    auto pop = [&]() {
-        cur = none;
-        while (sp > 0) {
-            --sp;
-            if (stack_t[sp] > best_d) continue;
-            enter(stack_i[sp]);
-            break;
-        }
-    };
-
-    if (work) {
-        enter(0u);
-        const float4* __restrict__ q = reinterpret_cast<const float4*>(kd);
-        float bound;
-        if (!slab_decide(T1, T2, T3, T4, T5, T6) || kd_prune(q[2], q[3], o, inv, oabs, best_d, bound)) cur = none;
-    }
-    while (cur != none) {
-        while (cur != none && (cb & kKdCountMask) == 0u) {
-            const uint32_t li = cur + 1u;
-            const bool has_l = li < ca; // ca = end of this subtree
-            const bool has_r = cr < ca;
-            const uint32_t ri = has_r ? cr : cur;
-            const float4* __restrict__ ql = reinterpret_cast<const float4*>(kd + (has_l ? li : cur));
-            const float4* __restrict__ qr = reinterpret_cast<const float4*>(kd + ri);
-            const float4 lh = ql[0], ly = ql[2], lz = ql[3];
-            const float4 rh = qr[0], ry = qr[2], rz = qr[3];
-            // the one new plane: both children's boxes are this node's box cut at `cs` on axis k
-            const uint32_t k = cb >> 30;
-            const float ok = k == 0u ? o.x : (k == 1u ? o.y : o.z);
-            const float dk = k == 0u ? d.x : (k == 1u ? d.y : d.z);
-            const float ts = (cs - ok) / dk;
-            const float L2 = k == 0u ? ts : T2, L4 = k == 1u ? ts : T4, L6 = k == 2u ? ts : T6; // left: max plane moved
-            const float R1 = k == 0u ? ts : T1, R3 = k == 1u ? ts : T3, R5 = k == 2u ? ts : T5; // right: min plane moved
-            float bl, br;
-            const bool el = has_l && slab_decide(T1, L2, T3, L4, T5, L6) && !kd_prune(ly, lz, o, inv, oabs, best_d, bl);
-            const bool er = has_r && slab_decide(R1, T2, R3, T4, R5, T6) && !kd_prune(ry, rz, o, inv, oabs, best_d, br);
-            const bool right_first = ((neg >> k) & 1u) != 0u;
-            const bool take_r = er && (right_first || !el);
-            if (el && er && sp < kKdStack) {
-                stack_i[sp] = take_r ? li : ri;
-                stack_t[sp] = take_r ? bl : br;
-                ++sp;
-            }
-            if (el || er) {
-                cur = take_r ? ri : li;
-                ca = __float_as_uint(take_r ? rh.x : lh.x);
-                cb = __float_as_uint(take_r ? rh.y : lh.y);
-                cr = __float_as_uint(take_r ? rh.z : lh.z);
-                cs = take_r ? rh.w : lh.w;
-                T1 = take_r ? R1 : T1; T2 = take_r ? T2 : L2;
-                T3 = take_r ? R3 : T3; T4 = take_r ? T4 : L4;
-                T5 = take_r ? R5 : T5; T6 = take_r ? T6 : L6;
-            } else {
-                pop();
-            }
-        }
-        if (cur != none) {
-            leaf_triangles(S, mesh.leaf_base + ca, cb & kKdCountMask, o, d, best_d, best_slot, found, bar_out, p_out);
-            pop();
-        }
-    }
+    KdWalk W;
+    walk_begin(W, S, mesh, o, d, work);
+    // results so far (a one-leaf root the caller already tested) carry over
+    W.best_d = best_d;
+    W.best_slot = best_slot;
+    W.found = found;
+    W.bar = bar_out;
+    W.p = p_out;
+    while (W.cur != kWalkNone) walk_round(W, S, true, stack_i, stack_t);
+    best_d = W.best_d;
+    best_slot = W.best_slot;
+    found = W.found;
+    bar_out = W.bar;
+    p_out = W.p;
 }
 
 // mesh::intersect (scene.cpp:115-121) for one lane.  `entered_root`: the caller has
@@ -881,10 +943,13 @@ __device__ __forceinline__ void tri_eval2(const float4 r0, const float4 r1, cons
     p_out = projection;
 }
 
-template <bool PRUNE>
+// SPLIT: KD-tree nodes are not walked here; the ones that survive the cull are returned as a bit
+// mask over DScene::tree_nodes (at most 64 of them) for the walker kernel (k_walk in ptk.hip).
+template <bool PRUNE, bool SPLIT>
 __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best,
-                                                         WaveLds& L)
+                                                         WaveLds& L, unsigned long long& tree_mask)
 {
+    tree_mask = 0ull;
     const uint32_t lane = lane_id();
     best.d0 = 3.402823466e+38f;
     best.node = -1;
@@ -1020,8 +1085,8 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
                 a = sp;
             }
         }
-        const bool is_tree = have && cls == kClassTree;
-        if (__builtin_amdgcn_ballot_w64(is_tree) != 0ull) {
+        const bool is_tree = !SPLIT && have && cls == kClassTree;
+        if (!SPLIT && __builtin_amdgcn_ballot_w64(is_tree) != 0ull) {
             const DMesh mesh = S.meshes[is_tree ? nd->mesh : 0u];
             int tprim = -1;
             V3 tb = mk(0.0f, 0.0f, 0.0f), tp = mk(0.0f, 0.0f, 0.0f);
@@ -1099,6 +1164,11 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             const bool facing_away =
                 __builtin_fmaf(d.x, cu->fn[0], __builtin_fmaf(d.y, cu->fn[1], d.z * cu->fn[2])) >= cu->ftau;
             const bool keep = lane_on && !(sane && (missed || t_out < 0.0f || facing_away));
+            if (SPLIT && cu->cls == kClassTree) { // wave-uniform branch
+                tree_mask |= keep ? (1ull << (cu->tree_slot & 63u)) : 0ull;
+                ++n;
+                continue;
+            }
             const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
             if (keep) L.queue[(qtail + mbcnt64(km)) & 127u] = (n << 6) | lane;
             qtail += (uint32_t)__popcll(km);
@@ -1134,7 +1204,10 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
 template <int MODE>
 __device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best, WaveLds* L)
 {
-    if (MODE & 8) intersect_scene_balanced<(MODE & 2) != 0>(S, o, d, lane_on, best, *L);
+    if (MODE & 8) {
+        unsigned long long unused;
+        intersect_scene_balanced<(MODE & 2) != 0, false>(S, o, d, lane_on, best, *L, unused);
+    }
     else if ((MODE & 5) == 5) intersect_scene_lanelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
     else if (MODE & 1) intersect_scene_nodelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
     else intersect_scene<(MODE & 2) != 0>(S, o, d, lane_on, best);

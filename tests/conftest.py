@@ -48,23 +48,27 @@ def _gpu_ctx_session():
     ctx.close()
 
 
-@pytest.fixture(params=[(2, 1, 2, 1), (2, 1, 2, 0), (1, 1, 1, 0), (1, 1, 0, 0), (0, 1, 2, 0), (2, 0, 1, 0), (2, 0, 2, 1)],
-                ids=["balanced", "lists-auto", "candidates", "nodelist", "uniform", "auto-refwalk-cull",
+@pytest.fixture(params=[(2, 1, 2, 1, 1), (2, 1, 2, 1, 0), (2, 1, 2, 0, 0), (1, 1, 1, 0, 0), (1, 1, 0, 0, 0), (0, 1, 2, 0, 0),
+                        (2, 0, 1, 0, 0), (2, 0, 2, 1, 0)],
+                ids=["split", "balanced", "lists-auto", "candidates", "nodelist", "uniform", "auto-refwalk-cull",
                      "balanced-refwalk"])
 def gpu_ctx(request, _gpu_ctx_session):
     """One ptk context on cuda:0 for the whole GPU session (the HIP library must load: no fallback);
-    every GPU test runs under every traversal mapping (PTK_OPT_BALANCE, PTK_OPT_TRAVERSAL x
-    PTK_OPT_NODE_CULL) with the pruned KD walk, and with the reference-order KD walk (PTK_OPT_KD_PRUNE = 0)."""
+    every GPU test runs under every traversal mapping (PTK_OPT_SPLIT, PTK_OPT_BALANCE, PTK_OPT_TRAVERSAL x
+    PTK_OPT_NODE_CULL) with the pruned KD walk, and with the reference-order KD walk (PTK_OPT_KD_PRUNE = 0).
+    "split" is the default configuration (the walker kernel runs wherever the scene has a KD-tree)."""
     from pathtracing_amd import _abi
     _gpu_ctx_session.set_option(_abi.PTK_OPT_TRAVERSAL, request.param[0])
     _gpu_ctx_session.set_option(_abi.PTK_OPT_KD_PRUNE, request.param[1])
     _gpu_ctx_session.set_option(_abi.PTK_OPT_NODE_CULL, request.param[2])
     _gpu_ctx_session.set_option(_abi.PTK_OPT_BALANCE, request.param[3])
+    _gpu_ctx_session.set_option(_abi.PTK_OPT_SPLIT, request.param[4])
     yield _gpu_ctx_session
     _gpu_ctx_session.set_option(_abi.PTK_OPT_TRAVERSAL, 2)
     _gpu_ctx_session.set_option(_abi.PTK_OPT_KD_PRUNE, 1)
     _gpu_ctx_session.set_option(_abi.PTK_OPT_NODE_CULL, 2)
     _gpu_ctx_session.set_option(_abi.PTK_OPT_BALANCE, 2)
+    _gpu_ctx_session.set_option(_abi.PTK_OPT_SPLIT, 2)
 
 
 def random_soup(n_tris, seed, extent=1.0, size=0.08):

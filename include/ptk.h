@@ -269,9 +269,8 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * PTK_OPT_SPLIT: scenes with KD-trees only (and PTK_OPT_KD_PRUNE, PTK_OPT_BALANCE on, at most 64 tree
  * nodes).  1 / 2 (default) = a bounce runs as two kernels: one casts every ray against the spheres and
  * one-leaf meshes and parks the rays that may hit a tree; a persistent walker kernel then walks the
- * trees of the parked rays, refilling lanes whose walk has ended, and shades them.  Ray queues are
- * appended to with one atomic per wave, so their order varies; every result is a function of the path
- * id and does not.  0 = the KD walk stays inside the bounce kernel. */
+ * trees of the parked rays, refilling lanes whose walk has ended; a third kernel shades the parked rays.
+ * 0 = the KD walk stays inside the bounce kernel.  Same results either way. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's
@@ -284,8 +283,9 @@ enum {
     PTK_KERNEL_BOUNCE_NEXT = 1,     /* k_bounce<false>: cast + shade, bounces 1..4        */
     PTK_KERNEL_ACCUMULATE = 2,      /* k_accumulate                                       */
     PTK_KERNEL_INTERSECT_BATCH = 3, /* k_intersect_batch (+ its walker in split mode)     */
-    PTK_KERNEL_WALK = 4,            /* k_walk: KD walks + shading of the parked rays      */
-    PTK_KERNEL_KINDS = 5
+    PTK_KERNEL_WALK = 4,            /* k_walk: KD walks of the parked rays (split mode)   */
+    PTK_KERNEL_SHADE_PARKED = 5,    /* k_shade_parked: their shading                      */
+    PTK_KERNEL_KINDS = 6
 };
 typedef struct ptk_kernel_timing {
     uint64_t launches;

@@ -262,27 +262,17 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
 // (ballot + mbcnt prefix); two queues alternate.  Queue order varies from run to run, results do not:
 // every path's random numbers and its sample_L slot are functions of its path id.
 struct SplitBufs {
-    float* q[2];                   // ray queues: kStateFields arrays of `cap` floats each
-    uint32_t* qcount;              // [PTK_MAX_DEPTH + 1] rays entering bounce b
-    uint32_t* pend_count;          // [PTK_MAX_DEPTH] parked rays of bounce b
-    uint32_t* pend_head;           // [PTK_MAX_DEPTH] next parked ray to hand out
-    uint32_t* pend_slot;           // queue slot (render) / ray index (batch) of a parked ray
-    unsigned long long* pend_mask; // its tree nodes: bits over DScene::tree_nodes
-    float* pend_best;              // 9 arrays of `cap`: d0, node, prim, a0..a2, pw of its best hit so far
+    float* q[2];                   // ray queues: kStateFields arrays of `cap` floats each, 256-slot segments
+    uint32_t* seg_count;           // [PTK_MAX_DEPTH][num_segments] live rays of a segment entering bounce b
+    uint32_t* seg_pend;            // [num_segments] parked rays of a segment (current bounce)
+    uint32_t* walk_head;           // [PTK_MAX_DEPTH] next segment chunk the walker hands out
+    uint32_t* pend_slot;           // per parked ray (segment * 256 + i): its queue slot (render) / ray index (batch)
+    unsigned long long* pend_mask; //   its tree nodes: bits over DScene::tree_nodes
+    float* pend_best;              //   9 arrays of `cap`: d0, node, prim, a0..a2, pw of its best hit so far
     uint64_t cap;
+    uint32_t num_segments;
 };
-
-// one atomic per wave; returns this lane's index (meaningful where `want` is set)
-__device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter)
-{
-    const uint64_t m = __builtin_amdgcn_ballot_w64(want);
-    if (m == 0ull) return 0u;
-    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-    uint32_t base = 0u;
-    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-    return base + mbcnt64(m);
-}
+constexpr uint32_t kSegChunk = 1; // segments the walker takes per atomic
 
 __device__ __forceinline__ void queue_store(float* __restrict__ q, uint64_t cap, uint32_t ws, V3 o, V3 d, V3 T, V3 L,
                                             uint32_t path)
@@ -308,14 +298,51 @@ __device__ __forceinline__ void park_ray(const SplitBufs& Q, uint32_t p, uint32_
     b[6 * cap + p] = h.pw.x; b[7 * cap + p] = h.pw.y; b[8 * cap + p] = h.pw.z;
 }
 
+// Positions of the flagged lanes packed over the whole workgroup (wave64 ballot + mbcnt prefix, then a
+// scan of the four wave counts through `counts`); needs one __syncthreads between fill and read.
+__device__ __forceinline__ uint32_t block_rank_fill(bool flag, uint32_t* counts, uint32_t& lane_rank)
+{
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(flag);
+    lane_rank = mbcnt64(mask);
+    if ((threadIdx.x & 63u) == 0u) counts[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    return (uint32_t)__popcll(mask);
+}
+__device__ __forceinline__ void block_rank_read(const uint32_t* counts, uint32_t& offset, uint32_t& total)
+{
+    const uint32_t wave = threadIdx.x >> 6;
+    offset = total = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        const uint32_t c = counts[w];
+        offset += (w < wave) ? c : 0u;
+        total += c;
+    }
+}
+
 template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_bounce_split(const DScene S, const DView V, const BounceArgs A, const SplitBufs Q)
 {
     __shared__ WaveLds wave_lds[kBlock / 64];
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t cnt = FIRST ? A.n_paths : Q.qcount[A.bounce];
-    if (blockIdx.x * kBlock >= cnt) return;
-    const bool on = slot < cnt;
+    __shared__ uint32_t alive_count[kBlock / 64], park_count[kBlock / 64];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t slot = seg * kBlock + tid;
+    const bool last = A.bounce + 1 >= PTK_MAX_DEPTH;
+    uint32_t cnt;
+    if (FIRST) {
+        const uint32_t base = seg * kBlock;
+        cnt = (A.n_paths > base) ? min((uint32_t)kBlock, A.n_paths - base) : 0u;
+    } else {
+        cnt = Q.seg_count[(size_t)A.bounce * Q.num_segments + seg];
+    }
+    if (cnt == 0u) {
+        if (tid == 0) {
+            Q.seg_pend[seg] = 0u;
+            if (!last) Q.seg_count[(size_t)(A.bounce + 1) * Q.num_segments + seg] = 0u;
+        }
+        return;
+    }
+    const bool on = tid < cnt;
     const uint64_t cap = A.cap;
     const float* __restrict__ qin = Q.q[A.bounce & 1u];
     float* __restrict__ qout = Q.q[(A.bounce + 1u) & 1u];
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_split(const DScene S, const D
         T = mk(1.0f, 1.0f, 1.0f);
         L = mk(0.0f, 0.0f, 0.0f);
     } else {
-        const uint32_t rs = on ? slot : 0u;
+        const uint32_t rs = on ? slot : seg * kBlock;
         o = mk(qin[0 * cap + rs], qin[1 * cap + rs], qin[2 * cap + rs]);
         d = mk(qin[3 * cap + rs], qin[4 * cap + rs], qin[5 * cap + rs]);
         T = mk(qin[6 * cap + rs], qin[7 * cap + rs], qin[8 * cap + rs]);
@@ -338,26 +365,34 @@ __global__ __launch_bounds__(kBlock) void k_bounce_split(const DScene S, const D
 
     Hit h;
     unsigned long long trees;
-    intersect_scene_balanced<true, true>(S, o, d, on, h, wave_lds[threadIdx.x >> 6], trees);
+    intersect_scene_balanced<true, true>(S, o, d, on, h, wave_lds[tid >> 6], trees);
 
     const bool parked = on && trees != 0ull;
-    const uint32_t p = wave_alloc(parked, Q.pend_count + A.bounce);
-    if (parked) {
-        park_ray(Q, p, slot, trees, h);
-        // bounce 0 has no input queue: the walker reads the generated ray from queue 0
-        if (FIRST) queue_store(Q.q[0], cap, slot, o, d, T, L, path);
-    }
+    // bounce 0 has no input queue: the walker reads the generated ray from queue 0
+    if (FIRST && parked) queue_store(Q.q[0], cap, slot, o, d, T, L, path);
     bool alive = false;
     if (on && !parked) alive = shade_ray(S, A, h, o, d, T, L, path);
-    if (A.bounce + 1 >= PTK_MAX_DEPTH) return;
-    const uint32_t ws = wave_alloc(alive, Q.qcount + A.bounce + 1u);
-    if (alive) queue_store(qout, cap, ws, o, d, T, L, path);
+
+    // parked rays and survivors are packed inside the segment (no global atomics, as in k_bounce)
+    uint32_t park_rank, alive_rank, park_off, park_total, alive_off, alive_total;
+    block_rank_fill(parked, park_count, park_rank);
+    block_rank_fill(alive, alive_count, alive_rank);
+    __syncthreads();
+    block_rank_read(park_count, park_off, park_total);
+    block_rank_read(alive_count, alive_off, alive_total);
+    if (tid == 0) {
+        Q.seg_pend[seg] = park_total;
+        if (!last) Q.seg_count[(size_t)(A.bounce + 1) * Q.num_segments + seg] = alive_total; // the walker adds its own
+    }
+    if (parked) park_ray(Q, seg * kBlock + park_off + park_rank, slot, trees, h);
+    if (alive) queue_store(qout, cap, seg * kBlock + alive_off + alive_rank, o, d, T, L, path);
 }
 
 // Parity-entry twin of k_bounce_split: rays from the caller's arrays, hits written out instead of shaded.
 __global__ __launch_bounds__(kBlock) void k_intersect_batch_split(const DScene S, const BatchIO B, const SplitBufs Q)
 {
     __shared__ WaveLds wave_lds[kBlock / 64];
+    __shared__ uint32_t park_count[kBlock / 64];
     const uint64_t n = B.n;
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool on = i < n;
@@ -368,8 +403,12 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch_split(const DScene S
     unsigned long long trees;
     intersect_scene_balanced<true, true>(S, ro, rd, on, h, wave_lds[threadIdx.x >> 6], trees);
     const bool parked = on && trees != 0ull;
-    const uint32_t p = wave_alloc(parked, Q.pend_count);
-    if (parked) park_ray(Q, p, (uint32_t)i, trees, h);
+    uint32_t park_rank, park_off, park_total;
+    block_rank_fill(parked, park_count, park_rank);
+    __syncthreads();
+    block_rank_read(park_count, park_off, park_total);
+    if (threadIdx.x == 0) Q.seg_pend[blockIdx.x] = park_total;
+    if (parked) park_ray(Q, blockIdx.x * kBlock + park_off + park_rank, (uint32_t)i, trees, h);
     if (on && !parked) write_batch_hit(S, B, i, h);
 }
 
@@ -379,24 +418,25 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch_split(const DScene S
 // are at least 33 lanes IDLE or DONE after the START/FIN step, so either 16 are IDLE (refill) or 17 are
 // DONE (shade); once the list is dry the walk loop runs the remaining lanes to the end.
 template <bool BATCH>
-__global__ __launch_bounds__(kBlock) void k_walk(const DScene S, const DView V, const BounceArgs A, const SplitBufs Q,
-                                                 const BatchIO B)
+__global__ __launch_bounds__(kBlock) void k_walk(const DScene S, const uint32_t bounce_in, const SplitBufs Q, const BatchIO B)
 {
     enum : uint32_t { IDLE = 0u, START = 1u, WALK = 2u, FIN = 3u, DONE = 4u };
+    __shared__ WalkLds wave_lds[kBlock / 64];
     const uint32_t lane = lane_id();
-    const uint32_t bounce = BATCH ? 0u : A.bounce;
-    const uint32_t pend_total = Q.pend_count[bounce];
+    const uint32_t bounce = BATCH ? 0u : bounce_in;
+    const uint32_t nseg = Q.num_segments;
     const uint64_t cap = Q.cap;
     const float* __restrict__ qin = Q.q[bounce & 1u];
-    float* __restrict__ qout = Q.q[(bounce + 1u) & 1u];
 
     uint32_t stack_i[kKdStack];
     float stack_t[kKdStack];
     KdWalk W;
     walk_begin(W, S, DMesh{ 0u, 0u, 0u, 0u }, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), false);
     uint32_t state = IDLE;
-    bool dry = pend_total == 0u; // wave-uniform: the list has been handed out completely
-    uint32_t slot = 0u, node = 0u;
+    // wave-uniform cursor over the parked lists: segments come in chunks of kSegChunk per atomic
+    bool dry = false;
+    uint32_t next_seg = 0u, chunk_end = 0u, seg_cur = 0u, pos = 0u, cnt = 0u;
+    uint32_t mine = 0u, node = 0u; // parked record of the lane's ray, tree node being walked
     unsigned long long trees = 0ull;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
     Hit best;
@@ -411,32 +451,54 @@ __global__ __launch_bounds__(kBlock) void k_walk(const DScene S, const DView V, 
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == IDLE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if (!dry && nidle >= 16u) {
-            const uint32_t leader = (uint32_t)__builtin_ctzll(idle);
-            uint32_t base = 0u;
-            if (lane == leader) base = atomicAdd(Q.pend_head + bounce, nidle);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-            const uint32_t mine = base + mbcnt64(idle);
-            if (state == IDLE && mine < pend_total) {
-                slot = Q.pend_slot[mine];
-                trees = Q.pend_mask[mine];
-                const float* __restrict__ pb = Q.pend_best;
-                best.d0 = pb[0 * cap + mine];
-                best.node = __float_as_int(pb[1 * cap + mine]);
-                best.prim = __float_as_int(pb[2 * cap + mine]);
-                best.a0 = pb[3 * cap + mine];
-                best.a1 = pb[4 * cap + mine];
-                best.a2 = pb[5 * cap + mine];
-                best.pw = mk(pb[6 * cap + mine], pb[7 * cap + mine], pb[8 * cap + mine]);
-                if (BATCH) {
-                    o = mk(B.o[slot], B.o[B.n + slot], B.o[2 * B.n + slot]);
-                    d = mk(B.d[slot], B.d[B.n + slot], B.d[2 * B.n + slot]);
-                } else {
-                    o = mk(qin[0 * cap + slot], qin[1 * cap + slot], qin[2 * cap + slot]);
-                    d = mk(qin[3 * cap + slot], qin[4 * cap + slot], qin[5 * cap + slot]);
+            uint64_t idle_left = idle;
+            while (idle_left != 0ull) {
+                while (!dry && pos >= cnt) { // on to the next segment that has parked rays
+                    if (next_seg >= chunk_end) {
+                        uint32_t base = 0u;
+                        if (lane == 0u) base = atomicAdd(Q.walk_head + bounce, kSegChunk);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        if (base >= nseg) {
+                            dry = true;
+                            break;
+                        }
+                        next_seg = base;
+                        chunk_end = base + kSegChunk < nseg ? base + kSegChunk : nseg;
+                    }
+                    seg_cur = next_seg++;
+                    cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.seg_pend[seg_cur]);
+                    pos = 0u;
                 }
-                state = START;
+                if (dry) break;
+                const uint32_t avail = cnt - pos, left = (uint32_t)__popcll(idle_left);
+                const uint32_t take = left < avail ? left : avail;
+                const bool mine_now = ((idle_left >> lane) & 1ull) != 0ull && mbcnt64(idle_left) < take;
+                if (mine_now) {
+                    mine = seg_cur * kBlock + pos + mbcnt64(idle_left);
+                    const uint32_t slot = Q.pend_slot[mine];
+                    trees = Q.pend_mask[mine];
+                    const float* __restrict__ pb = Q.pend_best;
+                    best.d0 = pb[0 * cap + mine];
+                    best.node = __float_as_int(pb[1 * cap + mine]);
+                    best.prim = __float_as_int(pb[2 * cap + mine]);
+                    best.a0 = pb[3 * cap + mine];
+                    best.a1 = pb[4 * cap + mine];
+                    best.a2 = pb[5 * cap + mine];
+                    best.pw = mk(pb[6 * cap + mine], pb[7 * cap + mine], pb[8 * cap + mine]);
+                    if (BATCH) {
+                        o = mk(B.o[slot], B.o[B.n + slot], B.o[2 * B.n + slot]);
+                        d = mk(B.d[slot], B.d[B.n + slot], B.d[2 * B.n + slot]);
+                    } else {
+                        o = mk(qin[0 * cap + slot], qin[1 * cap + slot], qin[2 * cap + slot]);
+                        d = mk(qin[3 * cap + slot], qin[4 * cap + slot], qin[5 * cap + slot]);
+                    }
+                    state = START;
+                }
+                PTK_STAT(S, 24, __popcll(__builtin_amdgcn_ballot_w64(mine_now)));
+                PTK_STAT(S, 25, 1);
+                idle_left &= ~__builtin_amdgcn_ballot_w64(mine_now);
+                pos += take;
             }
-            if (base + nidle >= pend_total) dry = true;
         }
 
         // FIN -> fold the node's result into the ray's best hit; START -> next tree node or DONE
@@ -467,39 +529,108 @@ __global__ __launch_bounds__(kBlock) void k_walk(const DScene S, const DView V, 
             }
         }
 
-        // walk
+        // walk.  Lanes on an interior node take descend steps while at least 24 of them are left; the
+        // lanes that reached a leaf wait and are then served together by the pooled leaf stage.
         const uint32_t walk_min = dry ? 1u : 32u;
-        while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == WALK)) >= walk_min) {
-            walk_round(W, S, state == WALK, stack_i, stack_t);
+        for (;;) {
             if (state == WALK && W.cur == kWalkNone) state = FIN;
-        }
-
-        // shade / write out the rays that are through
-        const uint32_t nbusy = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == WALK || state == FIN));
-        const uint32_t ndone = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == DONE));
-        if (ndone >= 17u || (ndone != 0u && dry && nbusy == 0u)) {
-            const bool fin = state == DONE;
-            if (BATCH) {
-                if (fin) write_batch_hit(S, B, slot, best);
+            const bool walking = state == WALK;
+            const bool at_leaf = walking && (W.cb & kKdCountMask) != 0u;
+            const bool at_node = walking && !at_leaf;
+            const uint32_t n_node = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_node));
+            const uint32_t n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_leaf));
+            if (n_node + n_leaf < walk_min || n_node + n_leaf == 0u) break;
+            if (n_node >= 24u || n_leaf == 0u) {
+                if (at_node) walk_descend_step(W, S, stack_i, stack_t);
             } else {
-                V3 T = mk(0.0f, 0.0f, 0.0f), L = T;
-                uint32_t path = 0u;
-                bool alive = false;
-                if (fin) {
-                    T = mk(qin[6 * cap + slot], qin[7 * cap + slot], qin[8 * cap + slot]);
-                    L = mk(qin[9 * cap + slot], qin[10 * cap + slot], qin[11 * cap + slot]);
-                    path = __float_as_uint(qin[12 * cap + slot]);
-                    alive = shade_ray(S, A, best, o, d, T, L, path);
-                }
-                if (bounce + 1u < PTK_MAX_DEPTH) {
-                    const uint32_t ws = wave_alloc(alive, Q.qcount + bounce + 1u);
-                    if (alive) queue_store(qout, cap, ws, o, d, T, L, path);
+                walk_leaf_stage(W, S, at_leaf, wave_lds[threadIdx.x >> 6]);
+                if (at_leaf && W.leaf_done >= (W.cb & kKdCountMask)) {
+                    W.leaf_done = 0u;
+                    walk_pop(W, stack_i, stack_t);
                 }
             }
-            if (fin) state = IDLE;
+        }
+
+        // a ray that is through hands its best hit back to its parked record (k_shade_parked /
+        // k_batch_parked pick it up with every lane busy) and frees the lane
+        if (state == DONE) {
+            float* __restrict__ pb = Q.pend_best;
+            pb[0 * cap + mine] = best.d0;
+            pb[1 * cap + mine] = __int_as_float(best.node);
+            pb[2 * cap + mine] = __int_as_float(best.prim);
+            pb[3 * cap + mine] = best.a0;
+            pb[4 * cap + mine] = best.a1;
+            pb[5 * cap + mine] = best.a2;
+            pb[6 * cap + mine] = best.pw.x;
+            pb[7 * cap + mine] = best.pw.y;
+            pb[8 * cap + mine] = best.pw.z;
+            state = IDLE;
         }
         if (dry && __builtin_amdgcn_ballot_w64(state != IDLE) == 0ull) break;
     }
+}
+
+// Shades the parked rays of a segment once the walker has finished their hits: dense again (one lane
+// per parked ray), survivors go behind the ones k_bounce_split left in the segment of the next queue.
+__global__ __launch_bounds__(kBlock) void k_shade_parked(const DScene S, const BounceArgs A, const SplitBufs Q)
+{
+    __shared__ uint32_t alive_count[kBlock / 64];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cnt = Q.seg_pend[seg];
+    if (cnt == 0u) return;
+    const bool on = tid < cnt;
+    const bool last = A.bounce + 1 >= PTK_MAX_DEPTH;
+    const uint64_t cap = A.cap;
+    const float* __restrict__ qin = Q.q[A.bounce & 1u];
+    float* __restrict__ qout = Q.q[(A.bounce + 1u) & 1u];
+    const uint32_t p = seg * kBlock + (on ? tid : 0u);
+    const uint32_t slot = Q.pend_slot[p];
+    const float* __restrict__ pb = Q.pend_best;
+    Hit h;
+    h.d0 = pb[0 * cap + p];
+    h.node = __float_as_int(pb[1 * cap + p]);
+    h.prim = __float_as_int(pb[2 * cap + p]);
+    h.a0 = pb[3 * cap + p];
+    h.a1 = pb[4 * cap + p];
+    h.a2 = pb[5 * cap + p];
+    h.pw = mk(pb[6 * cap + p], pb[7 * cap + p], pb[8 * cap + p]);
+    V3 o = mk(qin[0 * cap + slot], qin[1 * cap + slot], qin[2 * cap + slot]);
+    V3 d = mk(qin[3 * cap + slot], qin[4 * cap + slot], qin[5 * cap + slot]);
+    V3 T = mk(qin[6 * cap + slot], qin[7 * cap + slot], qin[8 * cap + slot]);
+    V3 L = mk(qin[9 * cap + slot], qin[10 * cap + slot], qin[11 * cap + slot]);
+    const uint32_t path = __float_as_uint(qin[12 * cap + slot]);
+    bool alive = false;
+    if (on) alive = shade_ray(S, A, h, o, d, T, L, path);
+    if (last) return;
+    uint32_t rank, off, total;
+    block_rank_fill(alive, alive_count, rank);
+    __syncthreads();
+    block_rank_read(alive_count, off, total);
+    uint32_t* __restrict__ next = Q.seg_count + (size_t)(A.bounce + 1) * Q.num_segments + seg;
+    const uint32_t base = *next; // what k_bounce_split left; only this workgroup touches the segment now
+    __syncthreads();
+    if (tid == 0) *next = base + total;
+    if (alive) queue_store(qout, cap, seg * kBlock + base + off + rank, o, d, T, L, path);
+}
+
+// parity-entry twin of k_shade_parked
+__global__ __launch_bounds__(kBlock) void k_batch_parked(const DScene S, const BatchIO B, const SplitBufs Q)
+{
+    const uint32_t seg = blockIdx.x;
+    if (threadIdx.x >= Q.seg_pend[seg]) return;
+    const uint64_t cap = Q.cap;
+    const uint32_t p = seg * kBlock + threadIdx.x;
+    const float* __restrict__ pb = Q.pend_best;
+    Hit h;
+    h.d0 = pb[0 * cap + p];
+    h.node = __float_as_int(pb[1 * cap + p]);
+    h.prim = __float_as_int(pb[2 * cap + p]);
+    h.a0 = pb[3 * cap + p];
+    h.a1 = pb[4 * cap + p];
+    h.a2 = pb[5 * cap + p];
+    h.pw = mk(pb[6 * cap + p], pb[7 * cap + p], pb[8 * cap + p]);
+    write_batch_hit(S, B, Q.pend_slot[p], h);
 }
 
 // abstract_pathtracer.cpp:70,85: color = sum over the pixel's samples.  One wave per
@@ -555,16 +686,6 @@ __global__ __launch_bounds__(kBlock) void k_tally(const uint32_t* __restrict__ s
         }
         atomicAdd(&counters[1], tot);
     }
-}
-
-// split mode: rays of a chunk = the queue counts of its bounces
-__global__ void k_tally_split(const uint32_t* __restrict__ qcount, uint32_t n_paths, unsigned long long* __restrict__ counters)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned long long rays = n_paths;
-    for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) rays += qcount[b];
-    atomicAdd(&counters[0], (unsigned long long)n_paths);
-    atomicAdd(&counters[1], rays);
 }
 
 // abstract_pathtracer.cpp:66,88-90
@@ -631,13 +752,15 @@ struct ptk_ctx {
 
     // split mode (scenes with KD-trees): second ray queue, parked-ray list, counters
     float* d_state2 = nullptr;
-    uint32_t* d_split_counters = nullptr; // qcount[PTK_MAX_DEPTH+1] pend_count[PTK_MAX_DEPTH] pend_head[PTK_MAX_DEPTH]
+    uint32_t* d_split_counters = nullptr; // walk_head[PTK_MAX_DEPTH]
+    uint32_t* d_seg_pend = nullptr;       // [cap / 256]
     uint32_t* d_pend_slot = nullptr;
     unsigned long long* d_pend_mask = nullptr;
     float* d_pend_best = nullptr;
     uint64_t split_cap = 0;
     // the same for ptk_intersect_batch_dev (sized by the largest batch so far)
-    uint32_t* d_bsplit_counters = nullptr;
+    uint32_t* d_bsplit_counters = nullptr; // walk_head
+    uint32_t* d_bseg_pend = nullptr;
     uint32_t* d_bpend_slot = nullptr;
     unsigned long long* d_bpend_mask = nullptr;
     float* d_bpend_best = nullptr;
@@ -681,6 +804,8 @@ void free_split(ptk_ctx* c)
 {
     if (c->d_state2) (void)hipFree(c->d_state2);
     if (c->d_split_counters) (void)hipFree(c->d_split_counters);
+    if (c->d_seg_pend) (void)hipFree(c->d_seg_pend);
+    c->d_seg_pend = nullptr;
     if (c->d_pend_slot) (void)hipFree(c->d_pend_slot);
     if (c->d_pend_mask) (void)hipFree(c->d_pend_mask);
     if (c->d_pend_best) (void)hipFree(c->d_pend_best);
@@ -693,6 +818,8 @@ void free_split(ptk_ctx* c)
 void free_batch_split(ptk_ctx* c)
 {
     if (c->d_bsplit_counters) (void)hipFree(c->d_bsplit_counters);
+    if (c->d_bseg_pend) (void)hipFree(c->d_bseg_pend);
+    c->d_bseg_pend = nullptr;
     if (c->d_bpend_slot) (void)hipFree(c->d_bpend_slot);
     if (c->d_bpend_mask) (void)hipFree(c->d_bpend_mask);
     if (c->d_bpend_best) (void)hipFree(c->d_bpend_best);
@@ -916,7 +1043,7 @@ bool split_mode(const ptk_ctx* c)
 }
 
 constexpr uint32_t kWalkBlocks = 1024; // persistent walker grid: 4 resident waves on each of the 1024 SIMDs
-constexpr uint32_t kSplitCounters = 3 * PTK_MAX_DEPTH + 1;
+constexpr uint32_t kSplitCounters = PTK_MAX_DEPTH;
 
 int set_device(ptk_ctx* c)
 {
@@ -1212,8 +1339,8 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
 #ifdef PTK_STATS
     {
         void* sp = nullptr;
-        PTK_HIP(c, hipMalloc(&sp, 16 * sizeof(unsigned long long)));
-        PTK_HIP(c, hipMemset(sp, 0, 16 * sizeof(unsigned long long)));
+        PTK_HIP(c, hipMalloc(&sp, 32 * sizeof(unsigned long long)));
+        PTK_HIP(c, hipMemset(sp, 0, 32 * sizeof(unsigned long long)));
         c->allocs.push_back(sp);
         S.stats = static_cast<unsigned long long*>(sp);
     }
@@ -1266,28 +1393,31 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
     const dim3 g(blocks), b(kBlock);
     if (split_mode(c) && n < 0xFFFFFFFFull) {
         // two kernels: everything but the KD-trees, then the walker over the parked rays
-        if (n > c->bsplit_cap) {
+        const uint64_t need = (uint64_t)blocks * kBlock;
+        if (need > c->bsplit_cap) {
             PTK_HIP(c, hipStreamSynchronize(c->stream));
             free_batch_split(c);
             PTK_HIP(c, hipMalloc((void**)&c->d_bsplit_counters, kSplitCounters * sizeof(uint32_t)));
-            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_slot, n * sizeof(uint32_t)));
-            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_mask, n * sizeof(unsigned long long)));
-            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_best, n * 9 * sizeof(float)));
-            c->bsplit_cap = n;
+            PTK_HIP(c, hipMalloc((void**)&c->d_bseg_pend, (need / kBlock) * sizeof(uint32_t)));
+            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_slot, need * sizeof(uint32_t)));
+            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_mask, need * sizeof(unsigned long long)));
+            PTK_HIP(c, hipMalloc((void**)&c->d_bpend_best, need * 9 * sizeof(float)));
+            c->bsplit_cap = need;
         }
         PTK_HIP(c, hipMemsetAsync(c->d_bsplit_counters, 0, kSplitCounters * sizeof(uint32_t), c->stream));
         SplitBufs Q{};
-        Q.qcount = c->d_bsplit_counters;
-        Q.pend_count = c->d_bsplit_counters + PTK_MAX_DEPTH + 1;
-        Q.pend_head = c->d_bsplit_counters + 2 * PTK_MAX_DEPTH + 1;
+        Q.seg_pend = c->d_bseg_pend;
+        Q.walk_head = c->d_bsplit_counters;
         Q.pend_slot = c->d_bpend_slot;
         Q.pend_mask = c->d_bpend_mask;
         Q.pend_best = c->d_bpend_best;
         Q.cap = c->bsplit_cap;
+        Q.num_segments = blocks;
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
         k_intersect_batch_split<<<g, b, 0, c->stream>>>(c->S, B, Q);
         const uint32_t wb = blocks < kWalkBlocks ? blocks : kWalkBlocks;
-        k_walk<true><<<dim3(wb), b, 0, c->stream>>>(c->S, c->V, BounceArgs{}, Q, B);
+        k_walk<true><<<dim3(wb), b, 0, c->stream>>>(c->S, 0u, Q, B);
+        k_batch_parked<<<g, b, 0, c->stream>>>(c->S, B, Q);
     } else {
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
 #define PTK_BATCH(M) k_intersect_batch<M><<<g, b, 0, c->stream>>>(c->S, B)
@@ -1414,6 +1544,7 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
         free_split(c);
         PTK_HIP(c, hipMalloc((void**)&c->d_state2, cap * kStateFields * sizeof(float)));
         PTK_HIP(c, hipMalloc((void**)&c->d_split_counters, kSplitCounters * sizeof(uint32_t)));
+        PTK_HIP(c, hipMalloc((void**)&c->d_seg_pend, (cap / kBlock) * sizeof(uint32_t)));
         PTK_HIP(c, hipMalloc((void**)&c->d_pend_slot, cap * sizeof(uint32_t)));
         PTK_HIP(c, hipMalloc((void**)&c->d_pend_mask, cap * sizeof(unsigned long long)));
         PTK_HIP(c, hipMalloc((void**)&c->d_pend_best, cap * 9 * sizeof(float)));
@@ -1445,9 +1576,10 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
                 SplitBufs Q{};
                 Q.q[0] = c->d_state;
                 Q.q[1] = c->d_state2;
-                Q.qcount = c->d_split_counters;
-                Q.pend_count = c->d_split_counters + PTK_MAX_DEPTH + 1;
-                Q.pend_head = c->d_split_counters + 2 * PTK_MAX_DEPTH + 1;
+                Q.seg_count = c->d_seg_count;
+                Q.seg_pend = c->d_seg_pend;
+                Q.walk_head = c->d_split_counters;
+                Q.num_segments = A.num_segments;
                 Q.pend_slot = c->d_pend_slot;
                 Q.pend_mask = c->d_pend_mask;
                 Q.pend_best = c->d_pend_best;
@@ -1460,8 +1592,12 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
                         if (b == 0) k_bounce_split<true><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
                         else k_bounce_split<false><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
                     }
-                    LaunchTimer lt(c, PTK_KERNEL_WALK);
-                    k_walk<false><<<dim3(wb), block, 0, c->stream>>>(c->S, c->V, A, Q, BatchIO{});
+                    {
+                        LaunchTimer lt(c, PTK_KERNEL_WALK);
+                        k_walk<false><<<dim3(wb), block, 0, c->stream>>>(c->S, b, Q, BatchIO{});
+                    }
+                    LaunchTimer lt(c, PTK_KERNEL_SHADE_PARKED);
+                    k_shade_parked<<<grid, block, 0, c->stream>>>(c->S, A, Q);
                 }
                 const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
                 {
@@ -1469,8 +1605,10 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
                     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, c->d_sample_L, cap,
                                        (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
                 }
-                hipLaunchKernelGGL(k_tally_split, dim3(1), dim3(64), 0, c->stream, c->d_split_counters, (uint32_t)n_paths,
-                                   c->d_counters);
+                const uint32_t entries = A.num_segments * (PTK_MAX_DEPTH - 1);
+                const uint32_t tally_blocks = entries / (kBlock * 8) + 1 > 256u ? 256u : entries / (kBlock * 8) + 1;
+                hipLaunchKernelGGL(k_tally, dim3(tally_blocks), dim3(kBlock), 0, c->stream,
+                                   c->d_seg_count + A.num_segments, entries, (uint32_t)n_paths, c->d_counters);
                 PTK_HIP(c, hipGetLastError());
                 continue;
             }
@@ -1694,8 +1832,8 @@ int ptk_debug_stats(ptk_ctx* c, unsigned long long* out16)
     if (!c || !out16 || !c->has_scene) return PTK_ERR_INVALID;
     if (int r = set_device(c)) return r;
     PTK_HIP(c, hipStreamSynchronize(c->stream));
-    PTK_HIP(c, hipMemcpy(out16, c->S.stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    PTK_HIP(c, hipMemset(c->S.stats, 0, 16 * sizeof(unsigned long long)));
+    PTK_HIP(c, hipMemcpy(out16, c->S.stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    PTK_HIP(c, hipMemset(c->S.stats, 0, 32 * sizeof(unsigned long long)));
     return PTK_OK;
 }
 #endif

@@ -124,7 +124,13 @@ struct DScene {
 #ifdef PTK_STATS
 #define PTK_STAT(S, k, v) do { if (lane_id() == 0u) atomicAdd((S).stats + (k), (unsigned long long)(v)); } while (0)
 #define PTK_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
+// inside divergent code: counts one event per wave (k) and the lanes taking part (k + 1)
+#define PTK_STAT_ACTIVE(S, k) do { const uint64_t m_ = __builtin_amdgcn_ballot_w64(true); \
+    if (lane_id() == (uint32_t)__builtin_ctzll(m_)) { atomicAdd((S).stats + (k), 1ull); atomicAdd((S).stats + (k) + 1, (unsigned long long)__popcll(m_)); } } while (0)
+#define PTK_STAT_ACTIVE_NS(k) do { } while (0)
 #else
+#define PTK_STAT_ACTIVE(S, k) do { } while (0)
+#define PTK_STAT_ACTIVE_NS(k) do { } while (0)
 #define PTK_STAT(S, k, v) do { } while (0)
 #define PTK_CLOCK() 0ull
 #endif
@@ -137,6 +143,16 @@ struct DView {
     float h2, w2;
     uint32_t width, height;
 };
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ uint32_t lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 
 // ---------------------------------------------------------------- vec helpers
 struct V3 {
@@ -266,6 +282,7 @@ __device__ __forceinline__ void leaf_triangles(const DScene& S, uint32_t first, 
                                                float& best_d, int& best_slot, bool& found, V3& bar_out, V3& p_out)
 {
     for (uint32_t k = 0; k < count; ++k) {
+        PTK_STAT_ACTIVE(S, 18);
         const float4* t = S.tri_hit + (size_t)(first + k) * 4;
         const float4 q0 = t[0], q1 = t[1], q2 = t[2], q3 = t[3];
         if (tri_test(q0, q1, q2, q3, o, d, (int)(first + k), best_d, best_slot, bar_out, p_out)) found = true;
@@ -354,6 +371,7 @@ struct KdWalk {
     float cs;
     float T1, T2, T3, T4, T5, T6; // its six slab quotients
     int sp;
+    uint32_t leaf_done;    // triangles of the current leaf already tested (walker kernel's pooled leaf stage)
     float best_d;
     int best_slot;
     bool found;
@@ -405,6 +423,7 @@ __device__ __forceinline__ void walk_begin(KdWalk& W, const DScene& S, const DMe
     W.cs = 0.0f;
     W.T1 = W.T2 = W.T3 = W.T4 = W.T5 = W.T6 = 0.0f;
     W.sp = 0;
+    W.leaf_done = 0u;
     W.best_d = 3.402823466e+38f;
     W.best_slot = -1;
     W.found = false;
@@ -418,55 +437,60 @@ __device__ __forceinline__ void walk_begin(KdWalk& W, const DScene& S, const DMe
     }
 }
 
-// One round for the lanes with `active` set: descend until every such lane stands on a leaf (or has
-// run out of nodes), then test those leaves and pop.
-__device__ __forceinline__ void walk_round(KdWalk& W, const DScene& S, bool active, uint32_t* stack_i, float* stack_t)
+// One descend step for a lane that stands on an interior node (the caller checks that).
+__device__ __forceinline__ void walk_descend_step(KdWalk& W, const DScene& S, uint32_t* stack_i, float* stack_t)
 {
+    PTK_STAT_ACTIVE(S, 16);
     const DKdNode* __restrict__ kd = W.kd;
     const V3 o = W.o, d = W.d;
-    while (active && W.cur != kWalkNone && (W.cb & kKdCountMask) == 0u) {
-        const uint32_t cur = W.cur, ca = W.ca, cb = W.cb, cr = W.cr;
-        const uint32_t li = cur + 1u;
-        const bool has_l = li < ca; // ca = end of this subtree
-        const bool has_r = cr < ca;
-        const uint32_t ri = has_r ? cr : cur;
-        const float4* __restrict__ ql = reinterpret_cast<const float4*>(kd + (has_l ? li : cur));
-        const float4* __restrict__ qr = reinterpret_cast<const float4*>(kd + ri);
-        const float4 lh = ql[0], ly = ql[2], lz = ql[3];
-        const float4 rh = qr[0], ry = qr[2], rz = qr[3];
-        // the one new plane: both children's boxes are this node's box cut at `cs` on axis k
-        const uint32_t k = cb >> 30;
-        const float ok = k == 0u ? o.x : (k == 1u ? o.y : o.z);
-        const float dk = k == 0u ? d.x : (k == 1u ? d.y : d.z);
-        const float ts = (W.cs - ok) / dk;
-        const float T1 = W.T1, T2 = W.T2, T3 = W.T3, T4 = W.T4, T5 = W.T5, T6 = W.T6;
-        const float L2 = k == 0u ? ts : T2, L4 = k == 1u ? ts : T4, L6 = k == 2u ? ts : T6; // left: max plane moved
-        const float R1 = k == 0u ? ts : T1, R3 = k == 1u ? ts : T3, R5 = k == 2u ? ts : T5; // right: min plane moved
-        float bl, br;
-        const bool el = has_l && slab_decide(T1, L2, T3, L4, T5, L6) && !kd_prune(ly, lz, o, W.inv, W.oabs, W.best_d, bl);
-        const bool er = has_r && slab_decide(R1, T2, R3, T4, R5, T6) && !kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
-        const bool right_first = ((W.neg >> k) & 1u) != 0u;
-        const bool take_r = er && (right_first || !el);
-        if (el && er && W.sp < kKdStack) {
-            stack_i[W.sp] = take_r ? li : ri;
-            stack_t[W.sp] = take_r ? bl : br;
-            ++W.sp;
-        }
-        if (el || er) {
-            W.cur = take_r ? ri : li;
-            W.ca = __float_as_uint(take_r ? rh.x : lh.x);
-            W.cb = __float_as_uint(take_r ? rh.y : lh.y);
-            W.cr = __float_as_uint(take_r ? rh.z : lh.z);
-            W.cs = take_r ? rh.w : lh.w;
-            W.T1 = take_r ? R1 : T1; W.T2 = take_r ? T2 : L2;
-            W.T3 = take_r ? R3 : T3; W.T4 = take_r ? T4 : L4;
-            W.T5 = take_r ? R5 : T5; W.T6 = take_r ? T6 : L6;
-        } else {
-            walk_pop(W, stack_i, stack_t);
-        }
+    const uint32_t cur = W.cur, ca = W.ca, cb = W.cb, cr = W.cr;
+    const uint32_t li = cur + 1u;
+    const bool has_l = li < ca; // ca = end of this subtree
+    const bool has_r = cr < ca;
+    const uint32_t ri = has_r ? cr : cur;
+    const float4* __restrict__ ql = reinterpret_cast<const float4*>(kd + (has_l ? li : cur));
+    const float4* __restrict__ qr = reinterpret_cast<const float4*>(kd + ri);
+    const float4 lh = ql[0], ly = ql[2], lz = ql[3];
+    const float4 rh = qr[0], ry = qr[2], rz = qr[3];
+    // the one new plane: both children's boxes are this node's box cut at `cs` on axis k
+    const uint32_t k = cb >> 30;
+    const float ok = k == 0u ? o.x : (k == 1u ? o.y : o.z);
+    const float dk = k == 0u ? d.x : (k == 1u ? d.y : d.z);
+    const float ts = (W.cs - ok) / dk;
+    const float T1 = W.T1, T2 = W.T2, T3 = W.T3, T4 = W.T4, T5 = W.T5, T6 = W.T6;
+    const float L2 = k == 0u ? ts : T2, L4 = k == 1u ? ts : T4, L6 = k == 2u ? ts : T6; // left: max plane moved
+    const float R1 = k == 0u ? ts : T1, R3 = k == 1u ? ts : T3, R5 = k == 2u ? ts : T5; // right: min plane moved
+    float bl, br;
+    const bool el = has_l && slab_decide(T1, L2, T3, L4, T5, L6) && !kd_prune(ly, lz, o, W.inv, W.oabs, W.best_d, bl);
+    const bool er = has_r && slab_decide(R1, T2, R3, T4, R5, T6) && !kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
+    const bool right_first = ((W.neg >> k) & 1u) != 0u;
+    const bool take_r = er && (right_first || !el);
+    if (el && er && W.sp < kKdStack) {
+        stack_i[W.sp] = take_r ? li : ri;
+        stack_t[W.sp] = take_r ? bl : br;
+        ++W.sp;
     }
-    if (active && W.cur != kWalkNone) {
-        leaf_triangles(S, W.leaf_base + W.ca, W.cb & kKdCountMask, o, d, W.best_d, W.best_slot, W.found, W.bar, W.p);
+    if (el || er) {
+        W.cur = take_r ? ri : li;
+        W.ca = __float_as_uint(take_r ? rh.x : lh.x);
+        W.cb = __float_as_uint(take_r ? rh.y : lh.y);
+        W.cr = __float_as_uint(take_r ? rh.z : lh.z);
+        W.cs = take_r ? rh.w : lh.w;
+        W.T1 = take_r ? R1 : T1; W.T2 = take_r ? T2 : L2;
+        W.T3 = take_r ? R3 : T3; W.T4 = take_r ? T4 : L4;
+        W.T5 = take_r ? R5 : T5; W.T6 = take_r ? T6 : L6;
+    } else {
+        walk_pop(W, stack_i, stack_t);
+    }
+}
+
+// One round of the closed per-lane loop: descend until the lane stands on a leaf (or has run out of
+// nodes), then test that leaf and pop.
+__device__ __forceinline__ void walk_round(KdWalk& W, const DScene& S, uint32_t* stack_i, float* stack_t)
+{
+    while (W.cur != kWalkNone && (W.cb & kKdCountMask) == 0u) walk_descend_step(W, S, stack_i, stack_t);
+    if (W.cur != kWalkNone) {
+        leaf_triangles(S, W.leaf_base + W.ca, W.cb & kKdCountMask, W.o, W.d, W.best_d, W.best_slot, W.found, W.bar, W.p);
         walk_pop(W, stack_i, stack_t);
     }
 }
@@ -484,7 +508,7 @@ __device__ __forceinline__ void kd_walk_pruned(const DScene& S, const DMesh mesh
     W.found = found;
     W.bar = bar_out;
     W.p = p_out;
-    while (W.cur != kWalkNone) walk_round(W, S, true, stack_i, stack_t);
+    while (W.cur != kWalkNone) walk_round(W, S, stack_i, stack_t);
     best_d = W.best_d;
     best_slot = W.best_slot;
     found = W.found;
@@ -867,14 +891,6 @@ struct alignas(16) WaveLds {
     uint32_t compact[64];            // window positions of the candidates in the current count group
 };
 
-__device__ __forceinline__ uint32_t lane_id()
-{
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 // value of `v` in lane `src` (every lane must be active)
 __device__ __forceinline__ float lane_get(float v, uint32_t src)
 {
@@ -1195,6 +1211,98 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         best.a1 = L.ray_pay[2][lane];
         best.a2 = L.ray_pay[3][lane];
         best.pw = mk(L.ray_pay[4][lane], L.ray_pay[5][lane], L.ray_pay[6][lane]);
+    }
+}
+
+// ---- pooled leaf stage of the walker kernel --------------------------------------------------
+// Leaves hold anything from one to dozens of triangles, so a per-lane triangle loop runs at the
+// pace of the largest leaf in the wave.  The walker (k_walk in ptk.hip) lets lanes that reached a
+// leaf wait until few lanes are still descending, then tests all waiting leaves together: the
+// (lane, triangle) pairs are numbered through an exclusive prefix sum of the leaf sizes and dealt
+// 64 at a time, item t going to lane t % 64.  The owner of an item is found without a search: every
+// waiting lane sets bit (start % 64) in the 64-bit word (start / 64) of `start_mask`; the owner of
+// item t is then the (number of starts at or before t)-th waiting lane.  Results are folded with
+// the same (squared distance, slot) LDS minimum as in the balanced traversal, then compared with
+// the lane's best so far exactly as tri_test does.  A lane contributes at most 64 triangles per
+// stage, so 64 words always suffice; a larger leaf simply takes several stages (KdWalk::leaf_done).
+struct alignas(16) WalkLds {
+    unsigned long long key[64];        // best (dd bits, slot) per lane this stage
+    unsigned long long start_mask[64]; // per 64-item chunk: bit i set = an owner's items start at item 64 * chunk + i
+    float pay[6][64];                  // bar, p of the lane's best triangle this stage
+    uint8_t owner[64];                 // k-th waiting lane
+};
+
+__device__ __forceinline__ uint32_t lane_get_u32(uint32_t v, uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+}
+
+// at_leaf: the lane stands on a leaf with triangles left to test.  Every lane of the wave calls this.
+__device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool at_leaf, WalkLds& L)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t left = at_leaf ? (W.cb & kKdCountMask) - W.leaf_done : 0u;
+    const uint32_t cnt = left < 64u ? left : 64u;
+    const uint32_t first = W.leaf_base + W.ca + W.leaf_done; // slot of the lane's first triangle this stage
+    // exclusive prefix sum of cnt over the lanes
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        incl += lane >= (uint32_t)off ? up : 0u;
+    }
+    const uint32_t start = incl - cnt;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint64_t wm = __builtin_amdgcn_ballot_w64(cnt != 0u);
+    if (total == 0u) return;
+    L.key[lane] = kKeyNone;
+    L.start_mask[lane] = 0ull;
+    if (cnt != 0u) L.owner[mbcnt64(wm)] = (uint8_t)lane;
+    wave_sync();
+    if (cnt != 0u) atomicOr(&L.start_mask[start >> 6], 1ull << (start & 63u));
+    wave_sync();
+    uint32_t before = 0u; // owners whose items start before the current chunk (wave-uniform)
+    for (uint32_t t0 = 0u; t0 < total; t0 += 64u) {
+        const unsigned long long m = L.start_mask[t0 >> 6];
+        const uint32_t t = t0 + lane;
+        const bool valid = t < total;
+        // starts at or before item t; at least one, because item 0 starts the first owner
+        const uint32_t k = before + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));
+        const uint32_t c = L.owner[valid ? k - 1u : 0u];
+        const uint32_t c_start = lane_get_u32(start, c), c_first = lane_get_u32(first, c);
+        const V3 co = lane_get(W.o, c), cd = lane_get(W.d, c);
+        const uint32_t slot = c_first + (valid ? t - c_start : 0u);
+        const float4* tp = S.tri_hit + (size_t)slot * 4;
+        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+        float dd = 0.0f;
+        V3 bar = mk(0.0f, 0.0f, 0.0f), p = mk(0.0f, 0.0f, 0.0f);
+        PTK_STAT(S, 18, 1);
+        const bool hit = valid && tri_eval(q0, q1, q2, q3, co, cd, dd, bar, p) && dd < 3.402823466e+38f;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | slot;
+        if (hit) atomicMin(&L.key[c], key);
+        wave_sync();
+        if (hit && L.key[c] == key) {
+            L.pay[0][c] = bar.x; L.pay[1][c] = bar.y; L.pay[2][c] = bar.z;
+            L.pay[3][c] = p.x;   L.pay[4][c] = p.y;   L.pay[5][c] = p.z;
+        }
+        before += (uint32_t)__popcll(m);
+    }
+    wave_sync();
+    if (cnt != 0u) {
+        const unsigned long long key = L.key[lane];
+        if (key != kKeyNone) {
+            // the bookkeeping of tri_test (scene.cpp:196-202) against the lane's best so far
+            const float dd = __uint_as_float((uint32_t)(key >> 32));
+            const int slot = (int)(uint32_t)key;
+            if (dd < W.best_d || (dd == W.best_d && slot < W.best_slot)) {
+                W.best_d = dd;
+                W.best_slot = slot;
+                W.found = true;
+                W.bar = mk(L.pay[0][lane], L.pay[1][lane], L.pay[2][lane]);
+                W.p = mk(L.pay[3][lane], L.pay[4][lane], L.pay[5][lane]);
+            }
+        }
+        W.leaf_done += cnt;
     }
 }
 

@@ -38,7 +38,7 @@ def main():
                 meta = {}
                 for r in csv.DictReader(open(f)):
                     k = short(r["Kernel_Name"])
-                    if "k_bounce" not in k and "k_intersect" not in k:
+                    if "k_bounce" not in k and "k_intersect" not in k and "k_walk" not in k:
                         continue
                     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                     meta[k] = {"VGPR": r.get("VGPR_Count") or r.get("Arch_VGPR_Count"), "SGPR": r.get("SGPR_Count"),

@@ -19,12 +19,14 @@ spp = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 scene = bench.load_workload(wl, 1_000_000)
 ctx = Context(0)
 ctx.set_option(4, 1)
+if len(sys.argv) > 4:
+    ctx.set_option(5, int(sys.argv[4]))
 ctx.upload(scene)
 ctx.render_begin(w, w, math.pi / 4)
 lib = _abi.load()
 lib.ptk_debug_stats.restype = C.c_int
 lib.ptk_debug_stats.argtypes = [C.c_void_p, C.c_void_p]
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 lib.ptk_debug_stats(ctx._h, out)
 total = torch.zeros(w, w, 3, device="cuda")
 ctx.render_samples_dev(0, 0, spp, total.data_ptr())
@@ -36,4 +38,9 @@ print(f"waves {v[0]}  candidates/wave {v[1]/waves:.1f}  batches/wave {v[2]/waves
       f"tri iterations/wave {v[4]/waves:.2f}  P/stage {v[6]/max(1,v[3]):.1f}  slots/stage {v[7]/max(1,v[3]):.1f}")
 print(f"cycles/wave: kernel(to shade end) {v[12]/waves:.0f}  intersect {v[11]/waves:.0f}  batches {v[9]/waves:.0f} (of which tri stages {v[10]/waves:.0f})  "
       f"=> cull loop {(v[11]-v[9])/waves:.0f}  batch excl tri {(v[9]-v[10])/waves:.0f}  shade+io {(v[12]-v[11])/waves:.0f}")
+if v[22]:
+    rays = max(1, v[24])
+    print(f"walker: parked rays {v[24]} in {v[25]} refills; rounds {v[22]} (avg walking lanes {v[23]/v[22]:.1f}); "
+          f"descend steps {v[16]} (avg lanes {v[17]/max(1,v[16]):.1f}, {v[17]/rays:.1f} per ray); "
+          f"leaf triangle steps {v[18]} (avg lanes {v[19]/max(1,v[18]):.1f}, {v[19]/rays:.1f} per ray)")
 ctx.close()

@@ -5,7 +5,7 @@ for d in sys.argv[1:]:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if 'k_bounce' not in k and 'k_intersect' not in k: continue
+            if 'k_bounce' not in k and 'k_intersect' not in k and 'k_walk' not in k: continue
             k = k.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
             acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, v in sorted(acc.items()):

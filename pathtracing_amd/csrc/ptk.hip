@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch_split(const DScene S
 // are at least 33 lanes IDLE or DONE after the START/FIN step, so either 16 are IDLE (refill) or 17 are
 // DONE (shade); once the list is dry the walk loop runs the remaining lanes to the end.
 template <bool BATCH>
-__global__ __launch_bounds__(kBlock) void k_walk(const DScene S, const uint32_t bounce_in, const SplitBufs Q, const BatchIO B)
+__global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32_t bounce_in, const SplitBufs Q, const BatchIO B)
 {
     enum : uint32_t { IDLE = 0u, START = 1u, WALK = 2u, FIN = 3u, DONE = 4u };
     __shared__ WalkLds wave_lds[kBlock / 64];
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const DScene S, const uint32_t 
                     }
                     state = START;
                 }
-                PTK_STAT(S, 24, __popcll(__builtin_amdgcn_ballot_w64(mine_now)));
+                PTK_STAT(S, 24, take);
                 PTK_STAT(S, 25, 1);
                 idle_left &= ~__builtin_amdgcn_ballot_w64(mine_now);
                 pos += take;
@@ -541,8 +541,12 @@ __global__ __launch_bounds__(kBlock) void k_walk(const DScene S, const uint32_t 
             const uint32_t n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_leaf));
             if (n_node + n_leaf < walk_min || n_node + n_leaf == 0u) break;
             if (n_node >= 24u || n_leaf == 0u) {
+                PTK_STAT(S, 22, 1);
+                PTK_STAT(S, 23, n_node);
                 if (at_node) walk_descend_step(W, S, stack_i, stack_t);
             } else {
+                PTK_STAT(S, 26, 1);
+                PTK_STAT(S, 27, n_leaf);
                 walk_leaf_stage(W, S, at_leaf, wave_lds[threadIdx.x >> 6]);
                 if (at_leaf && W.leaf_done >= (W.cb & kKdCountMask)) {
                     W.leaf_done = 0u;

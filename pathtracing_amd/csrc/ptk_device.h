@@ -1255,6 +1255,7 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const uint64_t wm = __builtin_amdgcn_ballot_w64(cnt != 0u);
     if (total == 0u) return;
+    PTK_STAT(S, 28, total);
     L.key[lane] = kKeyNone;
     L.start_mask[lane] = 0ull;
     if (cnt != 0u) L.owner[mbcnt64(wm)] = (uint8_t)lane;

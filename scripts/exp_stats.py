@@ -40,7 +40,7 @@ print(f"cycles/wave: kernel(to shade end) {v[12]/waves:.0f}  intersect {v[11]/wa
       f"=> cull loop {(v[11]-v[9])/waves:.0f}  batch excl tri {(v[9]-v[10])/waves:.0f}  shade+io {(v[12]-v[11])/waves:.0f}")
 if v[22]:
     rays = max(1, v[24])
-    print(f"walker: parked rays {v[24]} in {v[25]} refills; rounds {v[22]} (avg walking lanes {v[23]/v[22]:.1f}); "
-          f"descend steps {v[16]} (avg lanes {v[17]/max(1,v[16]):.1f}, {v[17]/rays:.1f} per ray); "
-          f"leaf triangle steps {v[18]} (avg lanes {v[19]/max(1,v[18]):.1f}, {v[19]/rays:.1f} per ray)")
+    print(f"walker: parked rays {v[24]} in {v[25]} refills; descend steps {v[22]} (avg lanes {v[23]/v[22]:.1f}, {v[23]/rays:.1f} per ray); "
+          f"leaf stages {v[26]} (avg leaf lanes {v[27]/max(1,v[26]):.1f}), triangle items {v[28]} ({v[28]/rays:.1f} per ray) in {v[18]} iterations "
+          f"({v[28]/max(1,v[18]):.1f} per iteration)")
 ctx.close()

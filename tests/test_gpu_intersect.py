@@ -216,3 +216,67 @@ def test_many_random_nodes(gpu_ctx):
     g, r = gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d)
     check_batch(g, r)
     assert (r["node"] >= 0).mean() > 0.25 and len(np.unique(r["node"])) > 30
+
+
+def _soup_node(S, tris, translate, axis, angle, scale):
+    node = S.SceneNode()
+    node.translate(np.asarray(translate, np.float32))
+    node.rotate(np.asarray(axis, np.float32), np.float32(angle))
+    node.scale(np.asarray(scale, np.float32))
+    node.shape = S.Mesh(tris)
+    return node
+
+
+def test_overlapping_trees_and_big_leaves(gpu_ctx):
+    """Split mode's walker (k_walk) on its awkward inputs: three overlapping KD-tree nodes (a parked ray
+    carries several tree bits, non-uniform scales make local and world distance orders differ), one of
+    them with 150 coincident triangles that the 1.5x rule keeps in one leaf (more than the 64 triangles
+    a lane contributes per pooled leaf stage), plus spheres and a cube the first kernel resolves."""
+    from oracle import oracle
+    from pathtracing_amd import scene as S
+    rng = np.random.default_rng(5)
+    sc = S.Scene()
+    cube = [n.shape for n in get_scene("room").nodes if isinstance(n.shape, S.Mesh)][-1]
+    clump = random_soup(1, 3, extent=0.2, size=0.5)
+    clump = np.repeat(clump, 150, axis=0)
+    clump[:, :, :3] += rng.normal(0, 1e-4, (150, 1, 3)).astype(np.float32)
+    big_leaf = np.concatenate([random_soup(4000, 11, extent=1.0, size=0.05), clump]).astype(np.float32)
+    sc.nodes.append(_soup_node(S, random_soup(20000, 21), [0.2, 0.0, -0.1], [0, 1, 0], 0.4, [1.0, 2.5, 0.6]))
+    sc.nodes.append(_soup_node(S, big_leaf, [-0.3, 0.2, 0.0], [1, 0.3, 0], 1.1, [1.4, 0.7, 1.0]))
+    sc.nodes.append(_soup_node(S, random_soup(6000, 31), [0.0, -0.1, 0.3], [0.2, 0.1, 1], 2.0, [0.5, 0.5, 3.0]))
+    for i in range(3):
+        node = S.SceneNode()
+        node.translate(rng.uniform(-1, 1, 3).astype(np.float32))
+        node.scale(np.full(3, 0.3, np.float32))
+        node.shape = S.Sphere() if i < 2 else cube
+        sc.nodes.append(node)
+    ora = oracle.OracleScene(sc)
+    gpu_ctx.upload(sc)
+    o, d = random_rays(300_000, 99, -2.5, 2.5)
+    g, r = gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d)
+    check_batch(g, r)
+    assert len(np.unique(r["node"][r["node"] >= 0])) == 6
+    # a second, much smaller batch reuses the walker's buffers
+    o, d = random_rays(777, 100, -2.5, 2.5)
+    check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d))
+
+
+def test_more_than_64_tree_nodes(gpu_ctx):
+    """70 KD-tree nodes do not fit the walker's 64-bit tree mask: the library falls back to the
+    in-kernel walk; ids stay exact."""
+    from oracle import oracle
+    from pathtracing_amd import scene as S
+    rng = np.random.default_rng(6)
+    sc = S.Scene()
+    mesh = S.Mesh(random_soup(400, 41, extent=1.0, size=0.1))
+    for i in range(70):
+        node = S.SceneNode()
+        node.translate(rng.uniform(-6, 6, 3).astype(np.float32))
+        node.rotate(rng.normal(0, 1, 3).astype(np.float32), np.float32(rng.uniform(0, 6.28)))
+        node.scale(rng.uniform(0.5, 1.5, 3).astype(np.float32))
+        node.shape = mesh
+        sc.nodes.append(node)
+    ora = oracle.OracleScene(sc)
+    gpu_ctx.upload(sc)
+    o, d = random_rays(200_000, 101, -8, 8)
+    check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d))

@@ -49,6 +49,29 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
 
 
+def load_pmc_traffic(workload):
+    """HBM bytes per launch of the traced kernels from the newest committed rocprofv3 PMC summary of this
+    workload (profiles/rNN_<tag>_pmc.json, written by scripts/collect_profiles.py from separate --pmc passes,
+    FETCH_SIZE doubled for gfx950's 128-B requests as MI355X_MICROARCH.md prescribes).  bench.py cannot
+    collect counters itself; an absent file gives traffic = null."""
+    import glob
+    tag = {"room": "room", "spheres": "spheres", "mario": "mario", "synthetic": "synth5m"}[workload]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")))
+    if not files:
+        return {}
+    out = {"source": os.path.relpath(files[-1], ROOT)}
+    with open(files[-1]) as f:
+        data = json.load(f)
+    for k, v in data.items():
+        d = v.get("derived", {})
+        if "hbm_read_bytes_per_dispatch" in d:
+            name = k.split(",")[0].replace("<false", "<false>").replace("<true", "<true>") if "k_bounce<" in k else k.split("<")[0]
+            if name.startswith("k_bounce_split"):
+                name = "k_bounce<false>" if "false" in k else "k_bounce<true>"
+            out[name] = d["hbm_read_bytes_per_dispatch"] + d.get("hbm_write_bytes_per_dispatch", 0.0)
+    return out
+
+
 def flops_from_stats(st, costs, equirect):
     """Algorithmic flops of a run from the oracle's operation counts (DESIGN.md 'Flop model')."""
     f = 0
@@ -223,31 +246,57 @@ def main():
             out["cpu_baseline"], model = cpu_baseline(scene, args.workload)
         else:
             out["cpu_baseline"] = None
-        # dominant kernel: k_bounce<false> (bounces 1..4), rank 0's launches
+        # dominant kernel, rank 0's launches: k_bounce<false> (bounces 1..4), or in split mode (scenes with
+        # KD-trees) the walker k_walk, which runs once per bounce
         n_launch, ms = timing["k_bounce<false>"]
         n0, ms0 = timing["k_bounce<true>"]
+        nw, msw = timing["k_walk"]
+        nsp, mssp = timing["k_shade_parked"]
+        pmc = load_pmc_traffic(args.workload)
         if n_launch and model is not None:
             rays_next = (rays - paths) / world / n_launch          # rays cast per k_bounce<false> launch
             avg_ms = ms / n_launch
             tflops = model["flops_per_ray"] * rays_next / (avg_ms * 1e-3) / 1e12
             gbs = model["bytes_per_ray"] * rays_next / (avg_ms * 1e-3) / 1e9
-            common = {"kernel": "k_bounce<false>", "traffic": None, "avg_launch_ms": avg_ms, "launches": n_launch,
+            common = {"kernel": "k_bounce<false>", "traffic": pmc.get("k_bounce<false>"), "traffic_source": pmc.get("source"),
+                      "avg_launch_ms": avg_ms, "launches": n_launch,
                       "rays_per_launch": rays_next, "first_bounce_avg_ms": (ms0 / n0) if n0 else None, **model}
+            if nw:
+                # split mode: one bounce = k_bounce_split (spheres, one-leaf meshes, parking) + k_walk (KD-trees
+                # of the parked rays) + k_shade_parked.  k_walk's algorithmic bytes: the KD nodes and triangle
+                # records of the pruned walk (64 B each) + the parked record in and out (76 + 36 B per ray).
+                rays_launch = rays / world / nw
+                walk_ms = msw / nw
+                walk_bytes = (64 * model["kd_nodes_per_ray"] + 64 * model["triangles_per_ray"] + 112) * rays_launch
+                bounce_ms = (ms + ms0 + msw + mssp) / nw
+                common.update({"kernel": "k_walk", "traffic": pmc.get("k_walk"), "avg_launch_ms": walk_ms, "launches": nw,
+                               "rays_per_launch": rays_launch,
+                               "bounce_kernels_avg_ms": {"k_bounce_split": (ms + ms0) / (n_launch + n0), "k_walk": walk_ms,
+                                                         "k_shade_parked": mssp / nsp if nsp else None},
+                               "bounce_algorithmic_GBs": model["bytes_per_ray"] * rays_launch / (bounce_ms * 1e-3) / 1e9})
+                gbs = walk_bytes / (walk_ms * 1e-3) / 1e9
+                tflops = model["flops_per_ray"] * rays_launch / (bounce_ms * 1e-3) / 1e12
             if args.workload in ("room", "spheres"):
                 # scene is scalar-cache resident: VALU issue bounds the kernel, not HBM
                 out["roofline"] = {
                     "bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": tflops / PEAK_FP32_TFLOPS, **common,
                     "hbm_algorithmic_GBs": gbs, "hbm_peak_GBs": PEAK_HBM_GBS,
-                    "note": "no MFMA on this path; peak = fp32 vector FMA peak, while hit arithmetic is built unfused "
-                            "(-ffp-contract=off, bit-exact ids) so 78.6 T un-fused op/s is the reachable ceiling",
+                    "note": "no MFMA on this path; peak = fp32 vector FMA peak with packed issue, while hit arithmetic is "
+                            "built unfused (-ffp-contract=off, bit-exact ids) so 78.6 T un-fused op/s is the reachable "
+                            "ceiling; flops are the REFERENCE's operation count per ray (it tests every node), the "
+                            "kernel's conservative cull skips most of them",
                 }
             else:
+                measured = (common["traffic"] / (common["avg_launch_ms"] * 1e-3) / 1e9) if common.get("traffic") else None
                 out["roofline"] = {
                     "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                     **common, "valu_algorithmic_TFLOPs": tflops,
-                    "note": "algorithmic bytes of the pruned KD walk (oracle walk model); divergent per-lane traversal "
-                            "keeps the kernel VALU/latency-bound well below the HBM roof (profiles/)",
+                    "hbm_measured_GBs": measured, "hbm_measured_frac": (measured / PEAK_HBM_GBS) if measured else None,
+                    "note": "achieved = algorithmic bytes of the pruned KD walk (oracle walk model: 64 B per node / triangle "
+                            "a ray touches) over the kernel's time; most of those fetches hit L2 / Infinity Cache (rays share "
+                            "the upper tree), so HBM traffic by PMC (traffic, hbm_measured_*) is far lower and the "
+                            "walker is bound by VALU issue of its divergent walk (valu_busy_frac in profiles/*_pmc.json)",
                 }
         else:
             out["roofline"] = None

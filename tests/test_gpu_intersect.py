@@ -280,3 +280,39 @@ def test_more_than_64_tree_nodes(gpu_ctx):
     gpu_ctx.upload(sc)
     o, d = random_rays(200_000, 101, -8, 8)
     check_batch(gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d))
+
+
+def test_mirrored_and_sheared_planes(gpu_ctx):
+    """The planar-mesh facing cull (DCull::fn, a ray direction that faces every triangle of a one-sided
+    planar mesh from behind cannot hit it) under transforms that flip orientation or shear: negative
+    scales, and a node matrix set directly to a sheared one.  Rays graze the planes at every angle."""
+    from oracle import oracle
+    from pathtracing_amd import scene as S
+    rng = np.random.default_rng(77)
+    room = get_scene("room")
+    meshes = [n.shape for n in room.nodes if isinstance(n.shape, S.Mesh)]
+    plane, cube = meshes[0], meshes[-1]
+    sc = S.Scene()
+    for i in range(24):
+        node = S.SceneNode()
+        node.translate(rng.uniform(-4, 4, 3).astype(np.float32))
+        node.rotate(rng.normal(0, 1, 3).astype(np.float32), np.float32(rng.uniform(0, 6.28)))
+        sgn = np.where(rng.uniform(0, 1, 3) < 0.4, -1.0, 1.0)
+        node.scale((sgn * rng.uniform(0.3, 3.0, 3)).astype(np.float32))
+        if i % 4 == 0:
+            shear = np.eye(4, dtype=np.float32)
+            shear[1][0] = np.float32(rng.uniform(-0.8, 0.8))  # column-major [col][row]
+            shear[2][1] = np.float32(rng.uniform(-0.8, 0.8))
+            node.multiply(shear)
+        node.shape = plane if i % 3 else cube
+        sc.nodes.append(node)
+    ora = oracle.OracleScene(sc)
+    gpu_ctx.upload(sc)
+    o, d = random_rays(400_000, 55, -6, 6)
+    # half of the rays start next to a plane and leave it at a shallow angle
+    centres = np.stack([n.transform[3][:3] for n in sc.nodes]).astype(np.float32)
+    k = len(o) // 2
+    o[:k] = centres[rng.integers(0, len(centres), k)] + rng.normal(0, 0.5, (k, 3)).astype(np.float32)
+    g, r = gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d)
+    check_batch(g, r)
+    assert (r["node"] >= 0).mean() > 0.2

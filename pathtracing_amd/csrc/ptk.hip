@@ -271,8 +271,8 @@ struct SplitBufs {
     float* pend_best;              //   9 arrays of `cap`: d0, node, prim, a0..a2, pw of its best hit so far
     uint64_t cap;
     uint32_t num_segments;
+    uint32_t walk_chunk;           // quarter-segment units the walker takes per atomic (host: ~12 grabs per wave)
 };
-constexpr uint32_t kSegChunk = 1; // segments the walker takes per atomic
 
 __device__ __forceinline__ void queue_store(float* __restrict__ q, uint64_t cap, uint32_t ws, V3 o, V3 d, V3 T, V3 L,
                                             uint32_t path)
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     __shared__ WalkLds wave_lds[kBlock / 64];
     const uint32_t lane = lane_id();
     const uint32_t bounce = BATCH ? 0u : bounce_in;
-    const uint32_t nseg = Q.num_segments;
+    const uint32_t nunits = Q.num_segments * 4u; // work units: quarters (64 slots) of the segments' parked lists
     const uint64_t cap = Q.cap;
     const float* __restrict__ qin = Q.q[bounce & 1u];
 
@@ -433,9 +433,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     KdWalk W;
     walk_begin(W, S, DMesh{ 0u, 0u, 0u, 0u }, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), false);
     uint32_t state = IDLE;
-    // wave-uniform cursor over the parked lists: segments come in chunks of kSegChunk per atomic
+    // wave-uniform cursor over the parked lists: units come in chunks of walk_chunk per atomic
     bool dry = false;
-    uint32_t next_seg = 0u, chunk_end = 0u, seg_cur = 0u, pos = 0u, cnt = 0u;
+    uint32_t next_unit = 0u, chunk_end = 0u, seg_cur = 0u, pos = 0u, cnt = 0u;
     uint32_t mine = 0u, node = 0u; // parked record of the lane's ray, tree node being walked
     unsigned long long trees = 0ull;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
@@ -453,21 +453,23 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
         if (!dry && nidle >= 16u) {
             uint64_t idle_left = idle;
             while (idle_left != 0ull) {
-                while (!dry && pos >= cnt) { // on to the next segment that has parked rays
-                    if (next_seg >= chunk_end) {
+                while (!dry && pos >= cnt) { // on to the next unit (a quarter of a segment's parked list) with rays
+                    if (next_unit >= chunk_end) {
                         uint32_t base = 0u;
-                        if (lane == 0u) base = atomicAdd(Q.walk_head + bounce, kSegChunk);
+                        if (lane == 0u) base = atomicAdd(Q.walk_head + bounce, Q.walk_chunk);
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        if (base >= nseg) {
+                        if (base >= nunits) {
                             dry = true;
                             break;
                         }
-                        next_seg = base;
-                        chunk_end = base + kSegChunk < nseg ? base + kSegChunk : nseg;
+                        next_unit = base;
+                        chunk_end = base + Q.walk_chunk < nunits ? base + Q.walk_chunk : nunits;
                     }
-                    seg_cur = next_seg++;
-                    cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.seg_pend[seg_cur]);
-                    pos = 0u;
+                    const uint32_t unit = next_unit++;
+                    seg_cur = unit >> 2;
+                    const uint32_t in_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.seg_pend[seg_cur]);
+                    pos = (unit & 3u) * 64u;
+                    cnt = in_seg < pos + 64u ? in_seg : pos + 64u;
                 }
                 if (dry) break;
                 const uint32_t avail = cnt - pos, left = (uint32_t)__popcll(idle_left);
@@ -1049,6 +1051,16 @@ bool split_mode(const ptk_ctx* c)
 constexpr uint32_t kWalkBlocks = 1024; // persistent walker grid: 4 resident waves on each of the 1024 SIMDs
 constexpr uint32_t kSplitCounters = PTK_MAX_DEPTH;
 
+// Walker work units are quarter segments; small launches take them one at a time (short tail), large
+// ones in chunks so that the single head counter sees about 12 atomics per resident wave.
+uint32_t walk_chunk_for(uint32_t num_segments)
+{
+    const uint64_t units = (uint64_t)num_segments * 4u;
+    const uint64_t chunk = units / (uint64_t(kWalkBlocks) * (kBlock / 64) * 12u);
+    if (chunk < 1u) return 1u;
+    return (uint32_t)(chunk >= 4u ? (chunk & ~3ull) : chunk); // whole segments once a grab spans one
+}
+
 int set_device(ptk_ctx* c)
 {
     PTK_HIP(c, hipSetDevice(c->device));
@@ -1417,6 +1429,7 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
         Q.pend_best = c->d_bpend_best;
         Q.cap = c->bsplit_cap;
         Q.num_segments = blocks;
+        Q.walk_chunk = walk_chunk_for(blocks);
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
         k_intersect_batch_split<<<g, b, 0, c->stream>>>(c->S, B, Q);
         const uint32_t wb = blocks < kWalkBlocks ? blocks : kWalkBlocks;
@@ -1584,6 +1597,7 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
                 Q.seg_pend = c->d_seg_pend;
                 Q.walk_head = c->d_split_counters;
                 Q.num_segments = A.num_segments;
+                Q.walk_chunk = walk_chunk_for(A.num_segments);
                 Q.pend_slot = c->d_pend_slot;
                 Q.pend_mask = c->d_pend_mask;
                 Q.pend_best = c->d_pend_best;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
 {
     __shared__ uint32_t wave_count[kBlock / 64];
     __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];
-    const unsigned long long kc0 = PTK_CLOCK();
+    [[maybe_unused]] const unsigned long long kc0 = PTK_CLOCK();
     const uint32_t seg = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t slot = seg * kBlock + tid;

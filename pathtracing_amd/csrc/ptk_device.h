@@ -438,7 +438,7 @@ __device__ __forceinline__ void walk_begin(KdWalk& W, const DScene& S, const DMe
 }
 
 // One descend step for a lane that stands on an interior node (the caller checks that).
-__device__ __forceinline__ void walk_descend_step(KdWalk& W, const DScene& S, uint32_t* stack_i, float* stack_t)
+__device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] const DScene& S, uint32_t* stack_i, float* stack_t)
 {
     PTK_STAT_ACTIVE(S, 16);
     const DKdNode* __restrict__ kd = W.kd;
@@ -975,7 +975,7 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
     L.ray_key[lane] = kKeyNone;
     uint32_t qhead = 0u, qtail = 0u; // (ray, node) ring, wave-uniform
     uint32_t shead = 0u, stail = 0u; // candidate ring, wave-uniform
-    const unsigned long long ic0 = PTK_CLOCK();
+    [[maybe_unused]] const unsigned long long ic0 = PTK_CLOCK();
 
     // scene.cpp:383-391 across nodes: keep the smallest (d0, node)
     auto commit = [&](bool hit, uint32_t owner, float d0, uint32_t n, int prim, V3 a, V3 pw) {
@@ -992,7 +992,7 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
 
     // stage 3: triangles of the first `cnt` stored candidates, then their hit -> world
     auto flush = [&](uint32_t cnt) {
-        const unsigned long long tc0 = PTK_CLOCK();
+        [[maybe_unused]] const unsigned long long tc0 = PTK_CLOCK();
         PTK_STAT(S, 3, 1);
         wave_sync();
         const bool have = lane < cnt;
@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
 
     // stage 2: lane i < cnt takes the i-th queued (ray, node) pair
     auto process = [&](uint32_t cnt) {
-        const unsigned long long pc0 = PTK_CLOCK();
+        [[maybe_unused]] const unsigned long long pc0 = PTK_CLOCK();
         PTK_STAT(S, 2, 1);
         wave_sync();
         const bool have = lane < cnt;

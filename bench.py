@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--node-cull", type=int, default=None, help="PTK_OPT_NODE_CULL override (0/1/2), for A/B runs")
     ap.add_argument("--balance", type=int, default=None, help="PTK_OPT_BALANCE override (0/1/2), for A/B runs")
     ap.add_argument("--split", type=int, default=None, help="PTK_OPT_SPLIT override (0/1/2), for A/B runs")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the N>1 path on a box with ONE GPU: every rank uses cuda:0 and the HDR sum "
+                         "buffers are reduced through host memory (not a measurement)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="room")
     ap.add_argument("--triangles", type=int, default=5_000_000, help="synthetic workload: triangle count")
     ap.add_argument("--resolution", type=int, nargs=2, default=None)
@@ -156,10 +159,15 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     distributed = world > 1
+    if args.backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     scene = load_workload(args.workload, args.triangles)
     drop = os.environ.get("PTK_BENCH_DROP")  # experiment knob: drop nodes by kind ("sphere", "leaf12", ...)
@@ -192,7 +200,11 @@ def main():
     def step(it):
         # rank r traces global samples [(it*world + r)*SPI, +SPI) of every pixel
         ctx.render_samples_dev(0, (it * world + rank) * SPI, SPI, total.data_ptr())
-        if distributed:
+        if distributed and args.backend == "gloo":
+            host = total.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            total.copy_(host)
+        elif distributed:
             dist.reduce(total, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
             ctx.resolve_iteration_dev(total.data_ptr(), image.data_ptr(), SPI * world, it)
@@ -217,7 +229,8 @@ def main():
     paths, rays = ctx.counters()
     timing = ctx.timing()
     ctx.enable_timing(False)
-    stats = torch.tensor([elapsed, float(paths), float(rays)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(paths), float(rays)], dtype=torch.float64,
+                         device="cpu" if args.backend == "gloo" else dev)
     if distributed:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)

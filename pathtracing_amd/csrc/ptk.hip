@@ -531,28 +531,37 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             }
         }
 
-        // walk.  Lanes on an interior node take descend steps while at least 24 of them are left; the
-        // lanes that reached a leaf wait and are then served together by the pooled leaf stage.
+        // walk.  A walking lane is in one of three places: on an interior node (next: a descend step), on a
+        // leaf (next: its triangles), or between nodes (next: a pop, which re-enters a node with six IEEE
+        // divides).  Each pass serves the most populated place for all its lanes at once, so the pooled
+        // leaf stage and the pops run for many lanes instead of being dragged along by every descend step.
         const uint32_t walk_min = dry ? 1u : 32u;
         for (;;) {
             if (state == WALK && W.cur == kWalkNone) state = FIN;
             const bool walking = state == WALK;
-            const bool at_leaf = walking && (W.cb & kKdCountMask) != 0u;
-            const bool at_node = walking && !at_leaf;
+            const bool at_pop = walking && W.cur == kWalkPop;
+            const bool at_leaf = walking && !at_pop && (W.cb & kKdCountMask) != 0u;
+            const bool at_node = walking && !at_pop && !at_leaf;
             const uint32_t n_node = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_node));
             const uint32_t n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_leaf));
-            if (n_node + n_leaf < walk_min || n_node + n_leaf == 0u) break;
-            if (n_node >= 24u || n_leaf == 0u) {
+            const uint32_t n_pop = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_pop));
+            const uint32_t n_walk = n_node + n_leaf + n_pop;
+            if (n_walk < walk_min || n_walk == 0u) break;
+            if (n_node >= 24u || (n_node >= n_leaf && n_node >= n_pop)) {
                 PTK_STAT(S, 22, 1);
                 PTK_STAT(S, 23, n_node);
-                if (at_node) walk_descend_step(W, S, stack_i, stack_t);
+                if (at_node) walk_descend_step<true>(W, S, stack_i, stack_t);
+            } else if (n_pop >= n_leaf) {
+                PTK_STAT(S, 29, 1);
+                PTK_STAT(S, 30, n_pop);
+                if (at_pop) walk_pop(W, stack_i, stack_t);
             } else {
                 PTK_STAT(S, 26, 1);
                 PTK_STAT(S, 27, n_leaf);
                 walk_leaf_stage(W, S, at_leaf, wave_lds[threadIdx.x >> 6]);
                 if (at_leaf && W.leaf_done >= (W.cb & kKdCountMask)) {
                     W.leaf_done = 0u;
-                    walk_pop(W, stack_i, stack_t);
+                    W.cur = kWalkPop;
                 }
             }
         }

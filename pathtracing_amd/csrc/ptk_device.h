@@ -361,6 +361,7 @@ __device__ __forceinline__ bool kd_prune(const float4 y, const float4 z, V3 o, V
 // them), so that the same code serves the closed per-lane loop (kd_walk_pruned) and the
 // walker kernel, which interleaves rounds with refilling idle lanes (k_walk in ptk.hip).
 constexpr uint32_t kWalkNone = 0xFFFFFFFFu;
+constexpr uint32_t kWalkPop = 0xFFFFFFFEu; // walker kernel only: the lane waits for its next stack entry (walk_pop)
 struct KdWalk {
     const DKdNode* kd;     // the mesh's first node
     uint32_t leaf_base;    // DMesh::leaf_base
@@ -437,7 +438,11 @@ __device__ __forceinline__ void walk_begin(KdWalk& W, const DScene& S, const DMe
     }
 }
 
-// One descend step for a lane that stands on an interior node (the caller checks that).
+// One descend step for a lane that stands on an interior node (the caller checks that).  DEFER_POP: a
+// lane whose two children both fail does not pop at once (a pop re-enters a node: six IEEE divides, for
+// the one or two lanes that need it) but parks itself as kWalkPop; the walker kernel pops such lanes
+// together.
+template <bool DEFER_POP>
 __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] const DScene& S, uint32_t* stack_i, float* stack_t)
 {
     PTK_STAT_ACTIVE(S, 16);
@@ -479,6 +484,8 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
         W.T1 = take_r ? R1 : T1; W.T2 = take_r ? T2 : L2;
         W.T3 = take_r ? R3 : T3; W.T4 = take_r ? T4 : L4;
         W.T5 = take_r ? R5 : T5; W.T6 = take_r ? T6 : L6;
+    } else if (DEFER_POP) {
+        W.cur = kWalkPop;
     } else {
         walk_pop(W, stack_i, stack_t);
     }
@@ -488,7 +495,7 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
 // nodes), then test that leaf and pop.
 __device__ __forceinline__ void walk_round(KdWalk& W, const DScene& S, uint32_t* stack_i, float* stack_t)
 {
-    while (W.cur != kWalkNone && (W.cb & kKdCountMask) == 0u) walk_descend_step(W, S, stack_i, stack_t);
+    while (W.cur != kWalkNone && (W.cb & kKdCountMask) == 0u) walk_descend_step<false>(W, S, stack_i, stack_t);
     if (W.cur != kWalkNone) {
         leaf_triangles(S, W.leaf_base + W.ca, W.cb & kKdCountMask, W.o, W.d, W.best_d, W.best_slot, W.found, W.bar, W.p);
         walk_pop(W, stack_i, stack_t);

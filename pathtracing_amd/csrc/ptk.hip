@@ -250,17 +250,19 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
 
 // ---- split mode: scenes with KD-trees -------------------------------------------------------
 // A ray's KD walk takes anything from zero to a few hundred node steps; inside k_bounce the wave
-// waits for its slowest lane.  Split mode (PTK_OPT_SPLIT) cuts a bounce in two kernels:
+// waits for its slowest lane.  Split mode (PTK_OPT_SPLIT) cuts a bounce in three kernels:
 //   k_bounce_split  casts every ray against the spheres and one-leaf meshes (balanced traversal) and
 //                   finds the KD-tree nodes it may hit (conservative cull).  Rays without such a node are
-//                   shaded at once; the others are parked: (queue slot, tree bit mask, best hit so far).
-//   k_walk          persistent waves take parked rays from that list, walk their trees and shade them.
-//                   A lane whose walk ends parks its result; when 16 lanes are free the wave fetches new
-//                   rays with one atomic, so the walk loop keeps at least half of the lanes busy until
-//                   the list runs dry (the "replace terminated rays" scheme of persistent traversal).
-// Surviving rays of both kernels are appended to the next bounce's queue with one atomic per wave
-// (ballot + mbcnt prefix); two queues alternate.  Queue order varies from run to run, results do not:
-// every path's random numbers and its sample_L slot are functions of its path id.
+//                   shaded at once; the others are parked: (queue slot, tree bit mask, best hit so far),
+//                   packed per 256-slot segment like the survivors (no global atomics).
+//   k_walk          persistent waves take parked rays (a quarter segment at a time, one atomic per grab)
+//                   and walk their trees.  A lane whose walk ends hands its hit back to the parked record;
+//                   when 24 lanes are free the wave fetches new rays, so the walk loop keeps 28 or more
+//                   lanes busy until the lists run dry ("replace terminated rays").
+//   k_shade_parked  shades the parked rays with every lane busy and packs the survivors behind the ones
+//                   k_bounce_split left in the segment of the next queue.
+// Two queues alternate between bounces.  Everything is packed in a fixed order, so split mode is as
+// deterministic as k_bounce.
 struct SplitBufs {
     float* q[2];                   // ray queues: kStateFields arrays of `cap` floats each, 256-slot segments
     uint32_t* seg_count;           // [PTK_MAX_DEPTH][num_segments] live rays of a segment entering bounce b
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
         // refill
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == IDLE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
-        if (!dry && nidle >= 16u) {
+        if (!dry && nidle >= 24u) {
             uint64_t idle_left = idle;
             while (idle_left != 0ull) {
                 while (!dry && pos >= cnt) { // on to the next unit (a quarter of a segment's parked list) with rays
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
         // leaf (next: its triangles), or between nodes (next: a pop, which re-enters a node with six IEEE
         // divides).  Each pass serves the most populated place for all its lanes at once, so the pooled
         // leaf stage and the pops run for many lanes instead of being dragged along by every descend step.
-        const uint32_t walk_min = dry ? 1u : 32u;
+        const uint32_t walk_min = dry ? 1u : 28u;
         for (;;) {
             if (state == WALK && W.cur == kWalkNone) state = FIN;
             const bool walking = state == WALK;
@@ -547,11 +549,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             const uint32_t n_pop = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_pop));
             const uint32_t n_walk = n_node + n_leaf + n_pop;
             if (n_walk < walk_min || n_walk == 0u) break;
-            if (n_node >= 24u || (n_node >= n_leaf && n_node >= n_pop)) {
+            // lanes served per instruction spent: a descend step costs about 135 VALU instructions, a pop 90,
+            // a leaf stage 250 or more
+            if (2u * n_node >= n_leaf && 2u * n_node >= 3u * n_pop) {
                 PTK_STAT(S, 22, 1);
                 PTK_STAT(S, 23, n_node);
                 if (at_node) walk_descend_step<true>(W, S, stack_i, stack_t);
-            } else if (n_pop >= n_leaf) {
+            } else if (3u * n_pop >= n_leaf) {
                 PTK_STAT(S, 29, 1);
                 PTK_STAT(S, 30, n_pop);
                 if (at_pop) walk_pop(W, stack_i, stack_t);

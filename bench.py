@@ -289,28 +289,23 @@ def main():
                                "bounce_algorithmic_GBs": model["bytes_per_ray"] * rays_launch / (bounce_ms * 1e-3) / 1e9})
                 gbs = walk_bytes / (walk_ms * 1e-3) / 1e9
                 tflops = model["flops_per_ray"] * rays_launch / (bounce_ms * 1e-3) / 1e12
-            if args.workload in ("room", "spheres"):
-                # scene is scalar-cache resident: VALU issue bounds the kernel, not HBM
-                out["roofline"] = {
-                    "bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / PEAK_FP32_TFLOPS, **common,
-                    "hbm_algorithmic_GBs": gbs, "hbm_peak_GBs": PEAK_HBM_GBS,
-                    "note": "no MFMA on this path; peak = fp32 vector FMA peak with packed issue, while hit arithmetic is "
-                            "built unfused (-ffp-contract=off, bit-exact ids) so 78.6 T un-fused op/s is the reachable "
-                            "ceiling; flops are the REFERENCE's operation count per ray (it tests every node), the "
-                            "kernel's conservative cull skips most of them",
-                }
-            else:
-                measured = (common["traffic"] / (common["avg_launch_ms"] * 1e-3) / 1e9) if common.get("traffic") else None
-                out["roofline"] = {
-                    "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                    **common, "valu_algorithmic_TFLOPs": tflops,
-                    "hbm_measured_GBs": measured, "hbm_measured_frac": (measured / PEAK_HBM_GBS) if measured else None,
-                    "note": "achieved = algorithmic bytes of the pruned KD walk (oracle walk model: 64 B per node / triangle "
-                            "a ray touches) over the kernel's time; most of those fetches hit L2 / Infinity Cache (rays share "
-                            "the upper tree), so HBM traffic by PMC (traffic, hbm_measured_*) is far lower and the "
-                            "walker is bound by VALU issue of its divergent walk (valu_busy_frac in profiles/*_pmc.json)",
-                }
+            measured = (common["traffic"] / (common["avg_launch_ms"] * 1e-3) / 1e9) if common.get("traffic") else None
+            note = ("no MFMA on this path; peak = fp32 vector FMA peak with packed issue, while hit arithmetic is built "
+                    "unfused (-ffp-contract=off, bit-exact ids) so 78.6 T un-fused op/s is the reachable ceiling; flops are "
+                    "the REFERENCE's operation count per ray (it tests every node and walks every box-hit KD node), the "
+                    "kernels' conservative cull and pruned walk skip most of them; VALU issue is the measured limiter "
+                    "(valu_busy_frac in profiles/*_pmc.json)")
+            if nw:
+                note += ("; split mode: achieved = flops per ray x rays per bounce over the three kernels of a bounce, "
+                         "kernel / avg_launch_ms / traffic are the walker's; hbm_algorithmic_GBs counts 64 B per KD node / "
+                         "triangle the pruned walk touches, mostly L2 / Infinity Cache hits (hbm_measured_* is PMC traffic)")
+            out["roofline"] = {
+                "bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / PEAK_FP32_TFLOPS, **common,
+                "hbm_algorithmic_GBs": gbs, "hbm_measured_GBs": measured,
+                "hbm_measured_frac": (measured / PEAK_HBM_GBS) if measured else None, "hbm_peak_GBs": PEAK_HBM_GBS,
+                "note": note,
+            }
         else:
             out["roofline"] = None
         print(json.dumps(out), flush=True)

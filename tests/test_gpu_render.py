@@ -187,3 +187,24 @@ def test_state_and_argument_errors(gpu_ctx):
         assert e.value.code == _abi.PTK_ERR_INVALID
     with pytest.raises(PtkError):
         Context(1000)
+
+
+@pytest.mark.parametrize("name,w,h,gpu_spp,cpu_spp", [("room", 16, 16, 524288, 262144), ("materials", 32, 32, 65536, 32768),
+                                                       ("mario", 12, 12, 524288, 131072)])
+def test_converged_image_matches_independent_cpu_render(_gpu_ctx_session, name, w, h, gpu_spp, cpu_spp):
+    """The north-star's statistical bar: a converged GPU image against a converged CPU (oracle) render that
+    shares NO samples with it (different seeds), relMSE <= 1e-3 on linear HDR.  Both estimate the same
+    integral, so what is left is Monte-Carlo noise of the two renders: without next-event estimation the
+    per-sample relative variance is about 76 (Room) / 35 (Mario), hence the sample counts (the reference's
+    own Room image is 64K spp) and the tiny frames, which put the noise at about a third of the bar; a
+    systematic difference (pixel convention, fov, weights, epsilon) would not average out."""
+    ctx = _gpu_ctx_session
+    ora = get_oracle(name)
+    ctx.upload(get_scene(name))
+    ctx.render_begin(w, h, FOV)
+    img = ctx.render_image(seed=1001, iterations=gpu_spp // 4096, spi=4096)
+    ref, _ = ora.render_image(w, h, FOV, 2002, cpu_spp // 4096, 4096, threads=16)
+    r = rel_mse(img, ref)
+    assert r <= 1e-3, r
+    # means agree much tighter than single pixels
+    assert abs(float(img.mean()) - float(ref.mean())) <= 0.01 * float(ref.mean()) + 1e-4

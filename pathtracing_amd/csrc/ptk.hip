@@ -127,12 +127,13 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
         float uvx, uvy, uu, vv;
         int prim_id;
         hit_attributes<false>(S, h, n, uvx, uvy, prim_id, uu, vv);
-        const DNode* __restrict__ nd = S.nodes + h.node;
         // pathtracer.cpp:34-37
-        const V3 albedo = sampler_sample(S, nd->albedo, uvx, uvy);
-        const V3 emission = sampler_sample(S, nd->emission, uvx, uvy);
-        const float roughness = sampler_sample(S, nd->roughness, uvx, uvy).x;
-        const float metallic = sampler_sample(S, nd->metallic, uvx, uvy).x;
+        const DSampler* __restrict__ ms = S.node_samplers + (size_t)h.node * 4;
+        const DSampler s_albedo = ms[0], s_emission = ms[1], s_roughness = ms[2], s_metallic = ms[3];
+        const V3 albedo = sampler_sample(S, s_albedo, uvx, uvy);
+        const V3 emission = sampler_sample(S, s_emission, uvx, uvy);
+        const float roughness = sampler_sample(S, s_roughness, uvx, uvy).x;
+        const float metallic = sampler_sample(S, s_metallic, uvx, uvy).x;
         L = L + mulv(T, emission);
         if (A.bounce + 1 < PTK_MAX_DEPTH) {
             const uint32_t pl = path / A.samples;
@@ -1184,7 +1185,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     std::vector<DMesh> meshes(sc->num_meshes);
     std::vector<DKdNode> kd;
     std::vector<float4> tri_hit, tri_shade;
-    std::vector<uint32_t> leaf_prim;
+    std::vector<uint32_t> leaf_prim, leaf_shade;
     c->kd_infos.resize(sc->num_meshes);
     std::vector<float> planar((size_t)sc->num_meshes * 4, 0.0f); // per mesh: shared face normal, flag
     bool deep_kd = false;
@@ -1269,6 +1270,8 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         tri_hit.resize(h0 + prims.size() * 4);
         for (size_t k = 0; k < prims.size(); ++k) std::memcpy(&tri_hit[h0 + k * 4], &rec[(size_t)prims[k] * 4], 64);
         leaf_prim.insert(leaf_prim.end(), prims.begin(), prims.end());
+        leaf_shade.resize(leaf_prim.size(), 0u); // padding slots included
+        for (size_t k = 0; k < prims.size(); ++k) leaf_shade[dm.leaf_base + k] = dm.shade_base + prims[k];
         const size_t s0 = tri_shade.size();
         tri_shade.resize(s0 + (size_t)md.num_triangles * 4);
         for (uint64_t t = 0; t < md.num_triangles; ++t) make_shade_record(md.triangles[t], &tri_shade[s0 + t * 4]);
@@ -1319,6 +1322,19 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
             culls[i] = make_cull_record(n, d, cond, nullptr);
         }
     }
+    std::vector<DLeaf> leaf_info(sc->num_nodes);
+    for (uint32_t i = 0; i < sc->num_nodes; ++i) {
+        DLeaf& lf = leaf_info[i];
+        std::memset(&lf, 0, sizeof(lf));
+        const ptk_node_desc& n = sc->nodes[i];
+        if (n.shape_kind == PTK_SHAPE_MESH && meshes[n.mesh].kd_count == 1u) {
+            const DKdNode& root = kd[meshes[n.mesh].kd_base];
+            std::memcpy(lf.cmin, root.cmin, 12);
+            std::memcpy(lf.cmax, root.cmax, 12);
+            lf.first = meshes[n.mesh].leaf_base + root.a;
+            lf.count = root.b_axis & kKdCountMask;
+        }
+    }
     std::vector<uint32_t> tree_nodes;
     for (uint32_t i = 0; i < sc->num_nodes; ++i)
         if (culls[i].cls == kClassTree) {
@@ -1352,8 +1368,21 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     if (int r = upload(c, tri_hit, &S.tri_hit)) return r;
     if (int r = upload(c, tri_pair, &S.tri_pair)) return r;
     if (int r = upload(c, leaf_prim, &S.leaf_prim)) return r;
+    if (int r = upload(c, leaf_shade, &S.leaf_shade)) return r;
+    if (int r = upload(c, leaf_info, &S.leaf_info)) return r;
     if (int r = upload(c, tri_shade, &S.tri_shade)) return r;
     if (int r = upload(c, samplers, &S.samplers)) return r;
+    {
+        std::vector<DSampler> node_samplers((size_t)sc->num_nodes * 4);
+        for (uint32_t i = 0; i < sc->num_nodes; ++i) {
+            const ptk_node_desc& n = sc->nodes[i];
+            node_samplers[(size_t)i * 4 + 0] = samplers[n.albedo];
+            node_samplers[(size_t)i * 4 + 1] = samplers[n.emission];
+            node_samplers[(size_t)i * 4 + 2] = samplers[n.roughness];
+            node_samplers[(size_t)i * 4 + 3] = samplers[n.metallic];
+        }
+        if (int r = upload(c, node_samplers, &S.node_samplers)) return r;
+    }
     if (int r = upload(c, textures, &S.textures)) return r;
     S.num_nodes = sc->num_nodes;
     S.bg_kind = sc->background.kind;

@@ -94,6 +94,14 @@ struct DSampler {
     uint32_t texture, mode, pad0, pad1;
 };
 
+// Root leaf of a one-leaf mesh node: the reference's root box (scene.cpp:190), first leaf slot, triangle count.
+struct alignas(16) DLeaf {
+    float cmin[3];
+    uint32_t first;
+    float cmax[3];
+    uint32_t count;
+};
+
 struct DTexture {
     const float* rgb;
     uint32_t w, h;
@@ -107,6 +115,13 @@ struct DScene {
     const float4* tri_hit;     // 4 float4 per leaf-ordered primitive
     const float4* tri_pair;    // 8 float4 per pair of leaf slots (2k, 2k+1) of the one-leaf meshes, interleaved
     const uint32_t* leaf_prim; // original triangle index per leaf-ordered primitive
+    // Copies that shorten dependent load chains (a wave waits for every link): what the balanced
+    // traversal needs of a one-leaf mesh node (instead of node -> mesh -> KD root), the shading record
+    // of a leaf slot (instead of node -> mesh, slot -> triangle), a node's four samplers (instead of
+    // node -> index -> sampler).
+    const struct DLeaf* leaf_info;    // per scene node
+    const uint32_t* leaf_shade;       // per leaf slot: index into tri_shade (shade_base + triangle)
+    const struct DSampler* node_samplers; // per scene node: albedo, emission, roughness, metallic
     const float4* tri_shade;   // 4 float4 per original triangle
     const DSampler* samplers;
     const DTexture* textures;
@@ -1131,11 +1146,11 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             // mesh::intersect on a root leaf: box test (scene.cpp:190); the triangles wait in the ring
             uint32_t count = 0u, first = 0u;
             if (is_leaf) {
-                const DMesh mesh = S.meshes[nd->mesh];
-                const DKdNode* __restrict__ kn = S.kd + mesh.kd_base;
-                if (box_intersect(kn->cmin[0], kn->cmin[1], kn->cmin[2], kn->cmax[0], kn->cmax[1], kn->cmax[2], lo, ld)) {
-                    count = kn->b_axis & kKdCountMask;
-                    first = mesh.leaf_base + kn->a;
+                const float4* __restrict__ lf = reinterpret_cast<const float4*>(S.leaf_info + n);
+                const float4 l0 = lf[0], l1 = lf[1];
+                if (box_intersect(l0.x, l0.y, l0.z, l1.x, l1.y, l1.z, lo, ld)) {
+                    count = __float_as_uint(l1.w);
+                    first = __float_as_uint(l0.w);
                 }
             }
             const uint64_t pm = __builtin_amdgcn_ballot_w64(count != 0u);
@@ -1344,9 +1359,8 @@ __device__ __forceinline__ void hit_attributes(const DScene& S, const Hit& h, V3
     uvx = uvy = 0.0f;
     prim_id = -1;
     if (h.prim >= 0) {
-        const DMesh mesh = S.meshes[nd->mesh];
-        const uint32_t tri = S.leaf_prim[h.prim];
-        const float4* s = S.tri_shade + (size_t)(mesh.shade_base + tri) * 4;
+        const uint32_t tri = ALWAYS_UV ? S.leaf_prim[h.prim] : 0u; // the triangle id is only reported by the parity entry
+        const float4* s = S.tri_shade + (size_t)S.leaf_shade[h.prim] * 4;
         const float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
         const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
         nl = n0 * h.a0 + n1 * h.a1 + n2 * h.a2;                           // scene.cpp:175-178
@@ -1397,9 +1411,8 @@ __device__ __forceinline__ V3 image_sample(const DTexture t, uint32_t mode, floa
 }
 
 // sampler_2d::sample: color_sampler (sampler.h:58) or image
-__device__ __forceinline__ V3 sampler_sample(const DScene& S, uint32_t idx, float u, float v)
+__device__ __forceinline__ V3 sampler_sample(const DScene& S, const DSampler sd, float u, float v)
 {
-    const DSampler sd = S.samplers[idx];
     if (sd.kind == PTK_SAMPLER_COLOR) return mk(sd.r, sd.g, sd.b);
     return image_sample(S.textures[sd.texture], sd.mode, u, v);
 }

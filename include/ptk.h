@@ -188,6 +188,15 @@ int ptk_kd_build_bounded(const ptk_triangle* triangles, uint64_t num_triangles,
                          ptk_kd_info* info, ptk_kd_node* nodes, uint64_t nodes_cap,
                          uint32_t* prims, uint64_t prims_cap);
 
+/* The same build on the GPU of `ctx` (kd_tree_node ctor scene.cpp:214-286, bounds
+ * of mesh::compile scene.cpp:123-137 when `bounds` is NULL).  `triangles` is a host pointer; nodes and
+ * prims come back to host memory, byte-identical to ptk_kd_build / ptk_kd_build_bounded.  Two-call
+ * pattern as above (each call builds).  num_triangles must be at least 1. */
+int ptk_kd_build_dev(ptk_ctx* ctx, const ptk_triangle* triangles, uint64_t num_triangles,
+                     const float* bounds /* 6 floats or NULL */, uint32_t root_depth,
+                     ptk_kd_info* info, ptk_kd_node* nodes, uint64_t nodes_cap,
+                     uint32_t* prims, uint64_t prims_cap);
+
 /* ---- closest hit for caller-supplied rays (parity entry) -----------------
  * scene::cast_ray (scene.cpp:355-399) for n rays.  SoA device arrays:
  * origins/directions are 3 arrays of n floats each laid out [x0..xn-1|y..|z..].
@@ -252,7 +261,7 @@ int ptk_reset_counters(ptk_ctx* ctx);
  * tested in the uniform loop and each lane then visits only the nodes whose box it pierced;
  * 2 (default) = 0 for the coherent primary rays of bounce 0 (1 if PTK_OPT_NODE_CULL applies), 1 for
  * later bounces and for ptk_intersect_batch.  No reference counterpart. */
-enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5 };
+enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5, PTK_OPT_DEVICE_KD = 6 };
 /* PTK_OPT_KD_PRUNE: how a multi-node KD-tree is walked (mesh::intersect_internal,
  * scene.cpp:188-212).  0 = the reference's order, every box-hit node is visited;
  * 1 (default) = near child first (by the sign of the ray direction on the split axis),
@@ -270,7 +279,10 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * nodes).  1 / 2 (default) = a bounce runs as two kernels: one casts every ray against the spheres and
  * one-leaf meshes and parks the rays that may hit a tree; a persistent walker kernel then walks the
  * trees of the parked rays, refilling lanes whose walk has ended; a third kernel shades the parked rays.
- * 0 = the KD walk stays inside the bounce kernel.  Same results either way. */
+ * 0 = the KD walk stays inside the bounce kernel.  Same results either way.
+ * PTK_OPT_DEVICE_KD: where ptk_scene_upload builds a mesh's KD-tree.  0 = host (ptk_kd_build's code),
+ * 1 = GPU (ptk_kd_build_dev's code), 2 (default) = GPU for meshes of at least 32768 triangles.  The two
+ * builders give byte-identical trees. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's

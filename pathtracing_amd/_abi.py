@@ -114,6 +114,7 @@ PTK_OPT_KD_PRUNE = 2
 PTK_OPT_NODE_CULL = 3
 PTK_OPT_BALANCE = 4
 PTK_OPT_SPLIT = 5
+PTK_OPT_DEVICE_KD = 6
 PTK_KERNEL_NAMES = ["k_bounce<true>", "k_bounce<false>", "k_accumulate", "k_intersect_batch", "k_walk", "k_shade_parked"]
 
 # name -> (restype, argtypes); every symbol include/ptk.h declares.
@@ -128,6 +129,8 @@ SYMBOLS = {
     "ptk_kd_build": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(KdInfo), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
     "ptk_kd_build_bounded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(KdInfo), C.c_void_p, C.c_uint64,
                                       C.c_void_p, C.c_uint64]),
+    "ptk_kd_build_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(KdInfo), C.c_void_p, C.c_uint64,
+                                  C.c_void_p, C.c_uint64]),
     "ptk_intersect_batch_dev": (C.c_int, [C.c_void_p, C.c_uint64] + [C.c_void_p] * 10),
     "ptk_intersect_batch": (C.c_int, [C.c_void_p, C.c_uint64] + [C.c_void_p] * 10),
     "ptk_render_begin": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64]),

@@ -26,6 +26,9 @@
 
 #include "ptk_device.h"
 
+int ptk_kd_build_device(hipStream_t stream, const ptk_triangle* triangles, uint64_t num_triangles, const float* bounds,
+                        uint32_t root_depth, ptk_kd_info* info, std::vector<ptk_kd_node>& nodes_out,
+                        std::vector<uint32_t>& prims_out, std::string* err); // kd_build_dev.hip
 void ptk_kd_build_vectors(const ptk_triangle* triangles, uint64_t num_triangles, ptk_kd_info* info,
                           std::vector<ptk_kd_node>& nodes, std::vector<uint32_t>& prims);
 
@@ -768,6 +771,7 @@ struct ptk_ctx {
     int node_cull = 2; // PTK_OPT_NODE_CULL
     int balance = 2;   // PTK_OPT_BALANCE
     int split = 2;     // PTK_OPT_SPLIT
+    int device_kd = 2; // PTK_OPT_DEVICE_KD
     uint32_t num_trees = 0; // nodes of class kClassTree
 
     // split mode (scenes with KD-trees): second ray queue, parked-ray list, counters
@@ -1075,6 +1079,8 @@ uint32_t walk_chunk_for(uint32_t num_segments)
     return (uint32_t)(chunk >= 4u ? (chunk & ~3ull) : chunk); // whole segments once a grab spans one
 }
 
+constexpr uint64_t kDeviceKdMinTriangles = 32768; // PTK_OPT_DEVICE_KD = 2: meshes at least this large build on the GPU
+
 int set_device(ptk_ctx* c)
 {
     PTK_HIP(c, hipSetDevice(c->device));
@@ -1194,9 +1200,19 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     std::vector<std::vector<ptk_kd_node>> built_nodes(sc->num_meshes);
     std::vector<std::vector<uint32_t>> built_prims(sc->num_meshes);
     std::vector<uint32_t> order;
-    for (uint32_t m = 0; m < sc->num_meshes; ++m)
-        ptk_kd_build_vectors(sc->meshes[m].triangles, sc->meshes[m].num_triangles, &c->kd_infos[m], built_nodes[m],
-                             built_prims[m]);
+    for (uint32_t m = 0; m < sc->num_meshes; ++m) {
+        const uint64_t nt = sc->meshes[m].num_triangles;
+        // small meshes: the host builder is done before a kernel would have launched
+        const bool on_device = nt != 0 && (c->device_kd == 1 || (c->device_kd == 2 && nt >= kDeviceKdMinTriangles));
+        if (on_device) {
+            std::string msg;
+            if (int r = ptk_kd_build_device(c->stream, sc->meshes[m].triangles, nt, nullptr, 0u, &c->kd_infos[m], built_nodes[m],
+                                            built_prims[m], &msg))
+                return fail(c, r, msg);
+        } else {
+            ptk_kd_build_vectors(sc->meshes[m].triangles, nt, &c->kd_infos[m], built_nodes[m], built_prims[m]);
+        }
+    }
     for (int pass = 0; pass < 2; ++pass)
         for (uint32_t m = 0; m < sc->num_meshes; ++m)
             if ((built_nodes[m].size() > 1) == (pass == 1)) order.push_back(m);
@@ -1802,11 +1818,39 @@ int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
         c->balance = value;
         return PTK_OK;
     }
+    if (option == PTK_OPT_DEVICE_KD && value >= 0 && value <= 2) {
+        c->device_kd = value;
+        return PTK_OK;
+    }
     if (option == PTK_OPT_KD_PRUNE && (value == 0 || value == 1)) {
         c->kd_prune = value;
         return PTK_OK;
     }
     return fail(c, PTK_ERR_INVALID, "ptk_ctx_set_option: unknown option or value");
+}
+
+int ptk_kd_build_dev(ptk_ctx* c, const ptk_triangle* triangles, uint64_t num_triangles, const float* bounds, uint32_t root_depth,
+                     ptk_kd_info* info, ptk_kd_node* nodes, uint64_t nodes_cap, uint32_t* prims, uint64_t prims_cap)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!triangles || num_triangles == 0)
+        return fail(c, PTK_ERR_INVALID, "ptk_kd_build_dev: no triangles (an empty mesh is one empty leaf: use ptk_kd_build)");
+    if (int r = set_device(c)) return r;
+    std::vector<ptk_kd_node> n;
+    std::vector<uint32_t> p;
+    ptk_kd_info local;
+    std::string msg;
+    if (int r = ptk_kd_build_device(c->stream, triangles, num_triangles, bounds, root_depth, &local, n, p, &msg)) return fail(c, r, msg);
+    if (info) *info = local;
+    if (nodes) {
+        if (nodes_cap < n.size()) return fail(c, PTK_ERR_INVALID, "ptk_kd_build_dev: nodes_cap too small");
+        std::memcpy(nodes, n.data(), n.size() * sizeof(ptk_kd_node));
+    }
+    if (prims) {
+        if (prims_cap < p.size()) return fail(c, PTK_ERR_INVALID, "ptk_kd_build_dev: prims_cap too small");
+        std::memcpy(prims, p.data(), p.size() * sizeof(uint32_t));
+    }
+    return PTK_OK;
 }
 
 int ptk_ctx_enable_timing(ptk_ctx* c, int enable)

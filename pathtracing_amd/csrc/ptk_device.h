@@ -137,7 +137,7 @@ struct DScene {
 #endif
 };
 #ifdef PTK_STATS
-#define PTK_STAT(S, k, v) do { if (lane_id() == 0u) atomicAdd((S).stats + (k), (unsigned long long)(v)); } while (0)
+#define PTK_STAT(S, k, v) do { if (lane_id() == 0u && (blockIdx.x & 15u) == 0u) atomicAdd((S).stats + (k), (unsigned long long)(v)); } while (0) // every 16th block: same-line atomics are slow enough to distort the clocks
 #define PTK_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
 // inside divergent code: counts one event per wave (k) and the lanes taking part (k + 1)
 #define PTK_STAT_ACTIVE(S, k) do { const uint64_t m_ = __builtin_amdgcn_ballot_w64(true); \

@@ -137,6 +137,20 @@ class Context:
     def reset_counters(self):
         self._check(self._lib.ptk_reset_counters(self._h))
 
+    def kd_build(self, triangles, bounds=None, root_depth=0):
+        """ptk_kd_build_dev: the KD build on this context's GPU -> (KdInfo, nodes ctypes array, prims ndarray),
+        byte-identical to kd_build() below."""
+        tris = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 8)
+        b = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.float32).reshape(6)
+        bp = None if b is None else b.ctypes.data
+        info = _abi.KdInfo()
+        self._check(self._lib.ptk_kd_build_dev(self._h, tris.ctypes.data, tris.shape[0], bp, root_depth, C.byref(info), None, 0, None, 0))
+        nodes = (_abi.KdNode * max(1, info.num_nodes))()
+        prims = np.empty(max(1, info.num_leaf_prims), np.uint32)
+        self._check(self._lib.ptk_kd_build_dev(self._h, tris.ctypes.data, tris.shape[0], bp, root_depth, C.byref(info),
+                                               C.cast(nodes, C.c_void_p), info.num_nodes, prims.ctypes.data, info.num_leaf_prims))
+        return info, nodes, prims[: info.num_leaf_prims]
+
 
 def kd_build(triangles):
     """ptk_kd_build on a (T,3,8) float32 array -> (KdInfo, nodes ctypes array, prims ndarray). Host only."""

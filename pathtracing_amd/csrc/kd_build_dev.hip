@@ -9,7 +9,7 @@
 //                  of the node's triangles IN ORDER, divided by float(3n) (scene.cpp:240-249).  fp32
 //                  addition does not reassociate, so the chain stays sequential: the wave stages 256
 //                  values at a time in LDS (coalesced loads, next block prefetched), then every lane
-//                  reads the same 16 bytes (LDS broadcast) and adds four values, ~4 cycles per value.
+//                  reads the same 16 bytes (LDS broadcast), sixteen reads ahead of the adds: ~4 cycles per value.
 //                  Only the top few levels have chains long enough to matter (15 M adds at the root of
 //                  a 5 M-triangle mesh); below that thousands of chains run side by side.
 //   k_classify     one thread per (node, triangle) entry: left if any vertex <= split, right if any
@@ -26,7 +26,10 @@
 // boxes for the pruned traversal (kd_build.cpp: fill_triangle_boxes), then one scatter into the
 // ptk_kd_node array.  Scans are rocPRIM device scans; one small read-back per level sizes the next
 // level's buffers.
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,7 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
 
-#include "../../include/ptk.h"
+#include "kd_build_dev.h"
 
 namespace {
 
@@ -55,6 +58,13 @@ template <typename T> struct DVec {
     T* p = nullptr;
     size_t cap = 0;
     ~DVec() { if (p) (void)hipFree(p); }
+    T* release()
+    {
+        T* r = p;
+        p = nullptr;
+        cap = 0;
+        return r;
+    }
     // room for `count` elements; `keep` of the old ones survive
     hipError_t reserve(size_t count, size_t keep, hipStream_t s)
     {
@@ -215,15 +225,23 @@ __global__ __launch_bounds__(256) void k_split_value(uint32_t K, const uint32_t*
         x2 = (nb + 128u + lane < total) ? v[nb + 128u + lane] : 0.0f;
         x3 = (nb + 192u + lane < total) ? v[nb + 192u + lane] : 0.0f;
         wave_sync_lds();
+        // 64 values at a time: sixteen 16-byte reads (the same address in every lane: LDS broadcast) are
+        // in flight before the first add, so the chain runs at the VALU's pace.  The block's unused tail
+        // holds +0.
         const uint64_t left = total - base;
-        const uint32_t quads = left >= 256u ? 64u : (uint32_t)((left + 3u) >> 2);
+        const uint32_t groups = left >= 256u ? 4u : (uint32_t)((left + 63u) >> 6);
         const float4* q4 = reinterpret_cast<const float4*>(b);
-        for (uint32_t q = 0; q < quads; ++q) {
-            const float4 t = q4[q]; // same address in every lane: LDS broadcast
-            acc += t.x;
-            acc += t.y;
-            acc += t.z;
-            acc += t.w;
+        for (uint32_t g = 0; g < groups; ++g) {
+            float4 t[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[q] = q4[g * 16u + q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc += t[q].x;
+                acc += t[q].y;
+                acc += t[q].z;
+                acc += t[q].w;
+            }
         }
         wave_sync_lds();
     }
@@ -515,18 +533,20 @@ inline uint32_t blocks_for(uint64_t n, uint32_t per) { return (uint32_t)((n + pe
 
 } // namespace
 
-// C++ entry used by ptk.hip.  `triangles` is a host pointer; `bounds` (6 floats, min then max) may be
-// null = mesh::compile's bounds.  Runs on the current device, on `stream`.  Device-side results stay
-// available to the caller through `keep_*` when given (not yet used).
-int ptk_kd_build_device(hipStream_t stream, const ptk_triangle* triangles, uint64_t num_triangles, const float* bounds,
-                        uint32_t root_depth, ptk_kd_info* info, std::vector<ptk_kd_node>& nodes_out,
-                        std::vector<uint32_t>& prims_out, std::string* err)
+int ptk_kd_build_device_keep(hipStream_t stream, const ptk_triangle* triangles, uint64_t num_triangles, const float* bounds,
+                             uint32_t root_depth, PtkDeviceTree* out, std::string* err)
 {
     if (num_triangles == 0 || num_triangles > 0xFFFFFFFFull / 4 || root_depth > PTK_KD_MAX_DEPTH) {
         if (err) *err = "ptk_kd_build_dev: triangle count or root depth out of range";
         return PTK_ERR_INVALID;
     }
     const uint32_t T = (uint32_t)num_triangles;
+    const bool trace = std::getenv("PTK_KD_TRACE") != nullptr; // phase times on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_begin = now();
     DVec<ptk_triangle> d_tris;
     DVec<float> d_pos, d_part, d_val[2], d_med;
     DVec<Box> d_root_box, d_box[2], d_tbox;
@@ -552,6 +572,8 @@ int ptk_kd_build_device(hipStream_t stream, const ptk_triangle* triangles, uint6
         k_bounds_final<<<1, 64, 0, stream>>>(d_part.p, pb, d_root_box.p);
     }
 
+    if (trace) (void)hipStreamSynchronize(stream);
+    const auto t_uploaded = now();
     int cur = 0;
     uint32_t E = T, K = 1, B = 0, leaf_total = 0, leaves = 0;
     std::vector<uint32_t> level_base, level_count;
@@ -623,6 +645,7 @@ int ptk_kd_build_device(hipStream_t stream, const ptk_triangle* triangles, uint6
     }
 
     // layout
+    const auto t_levels = now();
     const uint32_t levels = (uint32_t)level_base.size();
     KD_HIP(d_tbox.reserve(B, 0, stream));
     KD_HIP(d_size.reserve(B, 0, stream));
@@ -643,22 +666,48 @@ int ptk_kd_build_device(hipStream_t stream, const ptk_triangle* triangles, uint6
     if (leaf_total)
         k_emit_prims<<<blocks_for(leaf_total, 256), 256, 0, stream>>>(leaf_total, d_leaf_store.p, d_leaf_owner.p, d_kept.p, d_first.p, d_prims_out.p);
     KD_HIP(hipGetLastError());
+    if (trace) (void)hipStreamSynchronize(stream);
+    const auto t_layout = now();
 
-    nodes_out.resize(B);
-    prims_out.resize(leaf_total);
-    KD_HIP(hipMemcpyAsync(nodes_out.data(), d_nodes_out.p, (size_t)B * sizeof(ptk_kd_node), hipMemcpyDeviceToHost, stream));
-    if (leaf_total)
-        KD_HIP(hipMemcpyAsync(prims_out.data(), d_prims_out.p, (size_t)leaf_total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     Box root_box;
     KD_HIP(hipMemcpyAsync(&root_box, d_root_box.p, sizeof(Box), hipMemcpyDeviceToHost, stream));
     KD_HIP(hipStreamSynchronize(stream));
-    if (info) {
-        info->num_nodes = B;
-        info->num_leaves = leaves;
-        info->num_leaf_prims = leaf_total;
-        info->max_depth = root_depth + levels - 1u;
-        std::memcpy(info->bmin, root_box.lo, 12);
-        std::memcpy(info->bmax, root_box.hi, 12);
-    }
+    if (trace)
+        std::fprintf(stderr, "ptk_kd_build_dev: %u triangles: upload+bounds %.1f ms, %u levels %.1f ms, layout %.1f ms\n", T,
+                     ms(t_begin, t_uploaded), levels, ms(t_uploaded, t_levels), ms(t_levels, t_layout));
+    out->info.num_nodes = B;
+    out->info.num_leaves = leaves;
+    out->info.num_leaf_prims = leaf_total;
+    out->info.max_depth = root_depth + levels - 1u;
+    std::memcpy(out->info.bmin, root_box.lo, 12);
+    std::memcpy(out->info.bmax, root_box.hi, 12);
+    out->num_triangles = T;
+    out->tris = d_tris.release();
+    out->nodes = d_nodes_out.release();
+    out->prims = d_prims_out.release();
     return PTK_OK;
+}
+
+int ptk_kd_tree_download(hipStream_t stream, const PtkDeviceTree& tree, std::vector<ptk_kd_node>& nodes_out,
+                         std::vector<uint32_t>& prims_out, std::string* err)
+{
+    nodes_out.resize(tree.info.num_nodes);
+    prims_out.resize(tree.info.num_leaf_prims);
+    KD_HIP(hipMemcpyAsync(nodes_out.data(), tree.nodes, nodes_out.size() * sizeof(ptk_kd_node), hipMemcpyDeviceToHost, stream));
+    if (!prims_out.empty())
+        KD_HIP(hipMemcpyAsync(prims_out.data(), tree.prims, prims_out.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    KD_HIP(hipStreamSynchronize(stream));
+    return PTK_OK;
+}
+
+int ptk_kd_build_device(hipStream_t stream, const ptk_triangle* triangles, uint64_t num_triangles, const float* bounds,
+                        uint32_t root_depth, ptk_kd_info* info, std::vector<ptk_kd_node>& nodes_out,
+                        std::vector<uint32_t>& prims_out, std::string* err)
+{
+    PtkDeviceTree tree;
+    int r = ptk_kd_build_device_keep(stream, triangles, num_triangles, bounds, root_depth, &tree, err);
+    if (r == PTK_OK) r = ptk_kd_tree_download(stream, tree, nodes_out, prims_out, err);
+    if (r == PTK_OK && info) *info = tree.info;
+    tree.release();
+    return r;
 }

@@ -24,11 +24,9 @@
 #include <string>
 #include <vector>
 
+#include "kd_build_dev.h"
 #include "ptk_device.h"
 
-int ptk_kd_build_device(hipStream_t stream, const ptk_triangle* triangles, uint64_t num_triangles, const float* bounds,
-                        uint32_t root_depth, ptk_kd_info* info, std::vector<ptk_kd_node>& nodes_out,
-                        std::vector<uint32_t>& prims_out, std::string* err); // kd_build_dev.hip
 void ptk_kd_build_vectors(const ptk_triangle* triangles, uint64_t num_triangles, ptk_kd_info* info,
                           std::vector<ptk_kd_node>& nodes, std::vector<uint32_t>& prims);
 
@@ -880,17 +878,19 @@ int upload(ptk_ctx* c, const std::vector<T>& host, const T** out)
 struct HV3 {
     float x, y, z;
 };
-inline HV3 hsub(HV3 a, HV3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
-inline float hdot(HV3 a, HV3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-inline HV3 hcross(HV3 a, HV3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
-inline HV3 hnormalize(HV3 a)
+// host and device: the build flags make both sides round every operation alike (no contraction,
+// correctly rounded division and square root)
+__host__ __device__ inline HV3 hsub(HV3 a, HV3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+__host__ __device__ inline float hdot(HV3 a, HV3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ inline HV3 hcross(HV3 a, HV3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+__host__ __device__ inline HV3 hnormalize(HV3 a)
 {
-    const float s = 1.0f / std::sqrt(hdot(a, a));
+    const float s = 1.0f / sqrtf(hdot(a, a));
     return { a.x * s, a.y * s, a.z * s };
 }
 
 // triangle::update, scene.cpp:91-107 -> 64-B hit record
-void make_hit_record(const ptk_triangle& t, float4* q)
+__host__ __device__ void make_hit_record(const ptk_triangle& t, float4* q)
 {
     const HV3 p0 = { t.v[0].position[0], t.v[0].position[1], t.v[0].position[2] };
     const HV3 p1 = { t.v[1].position[0], t.v[1].position[1], t.v[1].position[2] };
@@ -905,12 +905,106 @@ void make_hit_record(const ptk_triangle& t, float4* q)
     q[3] = make_float4(d00, d01, d11, inv_den);
 }
 
-void make_shade_record(const ptk_triangle& t, float4* s)
+__host__ __device__ void make_shade_record(const ptk_triangle& t, float4* s)
 {
     s[0] = make_float4(t.v[0].normal[0], t.v[0].normal[1], t.v[0].normal[2], t.v[1].normal[0]);
     s[1] = make_float4(t.v[1].normal[1], t.v[1].normal[2], t.v[2].normal[0], t.v[2].normal[1]);
     s[2] = make_float4(t.v[2].normal[2], t.v[0].uv[0], t.v[0].uv[1], t.v[1].uv[0]);
     s[3] = make_float4(t.v[1].uv[1], t.v[2].uv[0], t.v[2].uv[1], 0.0f);
+}
+
+// ---- flattening of a tree that the GPU builder left in device memory (ptk_scene_upload) ----------
+// Same records as the host loops of ptk_scene_upload write for a host-built tree.
+
+// ptk_kd_node (preorder, skip links) -> DKdNode; max_leaf collects the largest leaf
+__global__ __launch_bounds__(256) void k_flat_kd(const ptk_kd_node* __restrict__ nodes, uint32_t count, DKdNode* __restrict__ out,
+                                                 uint32_t* __restrict__ max_leaf)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const ptk_kd_node n = nodes[i];
+    DKdNode k;
+    for (int a = 0; a < 3; ++a) {
+        k.cmin[a] = n.bmin[a];
+        k.cmax[a] = n.bmax[a];
+        k.tmin[a] = n.tmin[a];
+        k.tmax[a] = n.tmax[a];
+    }
+    const uint32_t axis = n.depth % 3u; // scene.cpp:230
+    k.split = 0.0f;
+    if (n.num_prims) {
+        k.a = n.first_prim;
+        k.b_axis = (n.num_prims & kKdCountMask) | (axis << 30);
+        k.right = n.skip;
+        if (n.num_prims > kKdCountMask) atomicMax(max_leaf, n.num_prims);
+    } else {
+        k.a = n.skip;
+        k.b_axis = axis << 30;
+        const bool has_left = i + 1 < count && i + 1 < n.skip;
+        k.right = has_left ? nodes[i + 1].skip : n.skip;
+        if (has_left) k.split = nodes[i + 1].bmax[axis];
+    }
+    out[i] = k;
+}
+
+// triangle::update (scene.cpp:91-107) and the shading record of every triangle, original order
+__global__ __launch_bounds__(256) void k_flat_records(const ptk_triangle* __restrict__ tris, uint32_t n, float4* __restrict__ rec,
+                                                      float4* __restrict__ shade)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const ptk_triangle tri = tris[t];
+    float4 q[4];
+    make_hit_record(tri, q);
+    for (int j = 0; j < 4; ++j) rec[(size_t)t * 4 + j] = q[j];
+    make_shade_record(tri, q);
+    for (int j = 0; j < 4; ++j) shade[(size_t)t * 4 + j] = q[j];
+}
+
+// leaf-ordered copies: hit record, triangle index, shading record index per leaf slot
+__global__ __launch_bounds__(256) void k_flat_leaves(const uint32_t* __restrict__ prims, uint32_t count, const float4* __restrict__ rec,
+                                                     uint32_t shade_base, float4* __restrict__ tri_hit, uint32_t* __restrict__ leaf_prim,
+                                                     uint32_t* __restrict__ leaf_shade)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; // one thread per 16 bytes
+    if (i >= (uint64_t)count * 4) return;
+    const uint32_t k = (uint32_t)(i >> 2), j = (uint32_t)(i & 3u);
+    const uint32_t t = prims[k];
+    tri_hit[i] = rec[(size_t)t * 4 + j];
+    if (j == 0u) {
+        leaf_prim[k] = t;
+        leaf_shade[k] = shade_base + t;
+    }
+}
+
+// planar mesh: every triangle::m_face_normal within 1e-6 of the first one (and that one finite)
+__global__ __launch_bounds__(256) void k_flat_planar(const ptk_triangle* __restrict__ tris, uint32_t n, uint32_t* __restrict__ differs,
+                                                     float* __restrict__ n0_out)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float4 q0[4], q[4];
+    make_hit_record(tris[0], q0);
+    make_hit_record(tris[t], q);
+    const float n0[3] = { q0[0].w, q0[1].x, q0[1].y }, nt[3] = { q[0].w, q[1].x, q[1].y };
+    bool same = isfinite(n0[0]) && isfinite(n0[1]) && isfinite(n0[2]);
+    for (int a = 0; a < 3; ++a) same = same && fabsf(nt[a] - n0[a]) <= 1e-6f; // false on NaN
+    if (!same) atomicOr(differs, 1u);
+    if (t == 0u)
+        for (int a = 0; a < 3; ++a) n0_out[a] = n0[a];
+}
+
+// a table with room for `extra` more elements behind the host part
+template <typename T>
+int upload_extra(ptk_ctx* c, const std::vector<T>& host, size_t extra, const T** out)
+{
+    const size_t count = host.size() + extra;
+    void* p = nullptr;
+    PTK_HIP(c, hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+    c->allocs.push_back(p);
+    if (!host.empty()) PTK_HIP(c, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return PTK_OK;
 }
 
 // Conservative world-space bounds of a node for the per-lane candidate lists
@@ -1200,22 +1294,36 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     std::vector<std::vector<ptk_kd_node>> built_nodes(sc->num_meshes);
     std::vector<std::vector<uint32_t>> built_prims(sc->num_meshes);
     std::vector<uint32_t> order;
+    // Large meshes are built on the GPU and stay there: their tables are written by kernels behind the
+    // host-built part of each table (k_flat_*), nothing of them comes back to the host.
+    struct DeviceTrees {
+        std::vector<PtkDeviceTree> t;
+        ~DeviceTrees() { for (PtkDeviceTree& x : t) x.release(); }
+    } dev;
+    dev.t.resize(sc->num_meshes);
     for (uint32_t m = 0; m < sc->num_meshes; ++m) {
         const uint64_t nt = sc->meshes[m].num_triangles;
         // small meshes: the host builder is done before a kernel would have launched
         const bool on_device = nt != 0 && (c->device_kd == 1 || (c->device_kd == 2 && nt >= kDeviceKdMinTriangles));
         if (on_device) {
             std::string msg;
-            if (int r = ptk_kd_build_device(c->stream, sc->meshes[m].triangles, nt, nullptr, 0u, &c->kd_infos[m], built_nodes[m],
-                                            built_prims[m], &msg))
-                return fail(c, r, msg);
+            if (int r = ptk_kd_build_device_keep(c->stream, sc->meshes[m].triangles, nt, nullptr, 0u, &dev.t[m], &msg)) return fail(c, r, msg);
+            c->kd_infos[m] = dev.t[m].info;
+            if (dev.t[m].info.num_nodes <= 1u) { // a one-leaf mesh goes through the pair table: host path
+                if (int r = ptk_kd_tree_download(c->stream, dev.t[m], built_nodes[m], built_prims[m], &msg)) return fail(c, r, msg);
+                dev.t[m].release();
+            }
         } else {
             ptk_kd_build_vectors(sc->meshes[m].triangles, nt, &c->kd_infos[m], built_nodes[m], built_prims[m]);
         }
     }
-    for (int pass = 0; pass < 2; ++pass)
-        for (uint32_t m = 0; m < sc->num_meshes; ++m)
-            if ((built_nodes[m].size() > 1) == (pass == 1)) order.push_back(m);
+    for (int pass = 0; pass < 3; ++pass)
+        for (uint32_t m = 0; m < sc->num_meshes; ++m) {
+            const int group = dev.t[m].nodes ? 2 : (built_nodes[m].size() > 1 ? 1 : 0);
+            if (group == pass) order.push_back(m);
+        }
+    size_t kd_extra = 0, leaf_extra = 0, shade_extra = 0; // device-built meshes, behind the host-built ones
+    std::vector<uint32_t> dev_planar; // per device-built mesh: differs flag + 3 floats, filled by k_flat_planar
     size_t one_leaf_slots = 0;
     for (uint32_t m : order) {
         const ptk_mesh_desc& md = sc->meshes[m];
@@ -1223,7 +1331,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         std::vector<uint32_t> prims;
         nodes.swap(built_nodes[m]);
         prims.swap(built_prims[m]);
-        if (nodes.size() <= 1) {
+        if (!dev.t[m].nodes && nodes.size() <= 1) {
             if (leaf_prim.size() & 1u) { // pad to an even slot (never referenced by a leaf)
                 leaf_prim.push_back(0u);
                 tri_hit.resize(tri_hit.size() + 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
@@ -1233,6 +1341,22 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         if (kd.size() + nodes.size() > 0xFFFFFFF0ull || leaf_prim.size() + prims.size() > 0x7FFFFFF0ull)
             return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: scene exceeds 32-bit table indices");
         DMesh& dm = meshes[m];
+        if (dev.t[m].nodes) {
+            // (order: every host-built mesh has been laid out by now)
+            const ptk_kd_info& ki = dev.t[m].info;
+            if (kd.size() + kd_extra + ki.num_nodes > 0xFFFFFFF0ull || leaf_prim.size() + leaf_extra + ki.num_leaf_prims > 0x7FFFFFF0ull)
+                return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: scene exceeds 32-bit table indices");
+            if (ki.max_depth > PTK_KD_MAX_DEPTH) return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: KD-tree deeper than PTK_KD_MAX_DEPTH");
+            dm.kd_base = (uint32_t)(kd.size() + kd_extra);
+            dm.kd_count = ki.num_nodes;
+            dm.leaf_base = (uint32_t)(leaf_prim.size() + leaf_extra);
+            dm.shade_base = (uint32_t)(tri_shade.size() / 4 + shade_extra);
+            kd_extra += ki.num_nodes;
+            leaf_extra += ki.num_leaf_prims;
+            shade_extra += md.num_triangles;
+            deep_kd = true;
+            continue;
+        }
         dm.kd_base = (uint32_t)kd.size();
         dm.kd_count = (uint32_t)nodes.size();
         dm.leaf_base = (uint32_t)leaf_prim.size();
@@ -1291,6 +1415,37 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         const size_t s0 = tri_shade.size();
         tri_shade.resize(s0 + (size_t)md.num_triangles * 4);
         for (uint64_t t = 0; t < md.num_triangles; ++t) make_shade_record(md.triangles[t], &tri_shade[s0 + t * 4]);
+    }
+    // planar test of the device-built meshes (make_cull_record below wants it)
+    {
+        uint32_t nd = 0;
+        for (uint32_t m = 0; m < sc->num_meshes; ++m) nd += dev.t[m].nodes ? 1u : 0u;
+        if (nd) {
+            uint32_t* d_flags = nullptr;
+            PTK_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_flags), (size_t)nd * 4 * sizeof(uint32_t)));
+            hipError_t e = hipMemsetAsync(d_flags, 0, (size_t)nd * 4 * sizeof(uint32_t), c->stream);
+            uint32_t k = 0;
+            for (uint32_t m = 0; m < sc->num_meshes && e == hipSuccess; ++m)
+                if (dev.t[m].nodes) {
+                    k_flat_planar<<<(dev.t[m].num_triangles + 255u) / 256u, 256, 0, c->stream>>>(
+                        dev.t[m].tris, dev.t[m].num_triangles, d_flags + (size_t)k * 4, reinterpret_cast<float*>(d_flags + (size_t)k * 4 + 1));
+                    ++k;
+                }
+            dev_planar.resize((size_t)nd * 4);
+            if (e == hipSuccess) e = hipMemcpyAsync(dev_planar.data(), d_flags, dev_planar.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            (void)hipFree(d_flags);
+            PTK_HIP(c, e);
+            k = 0;
+            for (uint32_t m = 0; m < sc->num_meshes; ++m)
+                if (dev.t[m].nodes) {
+                    if (dev_planar[(size_t)k * 4] == 0u) {
+                        std::memcpy(&planar[m * 4], &dev_planar[(size_t)k * 4 + 1], 12);
+                        planar[m * 4 + 3] = 1.0f;
+                    }
+                    ++k;
+                }
+        }
     }
     // Pair table of the one-leaf meshes (intersect_scene_balanced): slots 2k and 2k+1 interleaved
     // word by word, so one 16-B load yields two packed-fp32 operands.  An odd tail repeats itself.
@@ -1380,13 +1535,43 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     if (int r = upload(c, tree_nodes, &S.tree_nodes)) return r;
     S.num_trees = (uint32_t)tree_nodes.size();
     if (int r = upload(c, meshes, &S.meshes)) return r;
-    if (int r = upload(c, kd, &S.kd)) return r;
-    if (int r = upload(c, tri_hit, &S.tri_hit)) return r;
+    if (int r = upload_extra(c, kd, kd_extra, &S.kd)) return r;
+    if (int r = upload_extra(c, tri_hit, leaf_extra * 4, &S.tri_hit)) return r;
     if (int r = upload(c, tri_pair, &S.tri_pair)) return r;
-    if (int r = upload(c, leaf_prim, &S.leaf_prim)) return r;
-    if (int r = upload(c, leaf_shade, &S.leaf_shade)) return r;
+    if (int r = upload_extra(c, leaf_prim, leaf_extra, &S.leaf_prim)) return r;
+    if (int r = upload_extra(c, leaf_shade, leaf_extra, &S.leaf_shade)) return r;
     if (int r = upload(c, leaf_info, &S.leaf_info)) return r;
-    if (int r = upload(c, tri_shade, &S.tri_shade)) return r;
+    if (int r = upload_extra(c, tri_shade, shade_extra * 4, &S.tri_shade)) return r;
+    for (uint32_t m = 0; m < sc->num_meshes; ++m)
+        if (dev.t[m].nodes) {
+            const PtkDeviceTree& t = dev.t[m];
+            const DMesh& dm = meshes[m];
+            float4* rec = nullptr;
+            uint32_t* d_max_leaf = nullptr;
+            PTK_HIP(c, hipMalloc(reinterpret_cast<void**>(&rec), (size_t)t.num_triangles * 64));
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_max_leaf), sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemsetAsync(d_max_leaf, 0, sizeof(uint32_t), c->stream);
+            uint32_t max_leaf = 0;
+            if (e == hipSuccess) {
+                k_flat_kd<<<(t.info.num_nodes + 255u) / 256u, 256, 0, c->stream>>>(t.nodes, t.info.num_nodes,
+                                                                                   const_cast<DKdNode*>(S.kd) + dm.kd_base, d_max_leaf);
+                k_flat_records<<<(t.num_triangles + 255u) / 256u, 256, 0, c->stream>>>(
+                    t.tris, t.num_triangles, rec, const_cast<float4*>(S.tri_shade) + (size_t)dm.shade_base * 4);
+                const uint64_t quads = t.info.num_leaf_prims * 4;
+                if (quads)
+                    k_flat_leaves<<<(uint32_t)((quads + 255u) / 256u), 256, 0, c->stream>>>(
+                        t.prims, (uint32_t)t.info.num_leaf_prims, rec, dm.shade_base, const_cast<float4*>(S.tri_hit) + (size_t)dm.leaf_base * 4,
+                        const_cast<uint32_t*>(S.leaf_prim) + dm.leaf_base, const_cast<uint32_t*>(S.leaf_shade) + dm.leaf_base);
+                e = hipMemcpyAsync(&max_leaf, d_max_leaf, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipGetLastError();
+            (void)hipFree(rec);
+            if (d_max_leaf) (void)hipFree(d_max_leaf);
+            PTK_HIP(c, e);
+            if (max_leaf) return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: leaf too large");
+            dev.t[m].release();
+        }
     if (int r = upload(c, samplers, &S.samplers)) return r;
     {
         std::vector<DSampler> node_samplers((size_t)sc->num_nodes * 4);

@@ -150,3 +150,49 @@ def test_scene_upload_uses_either_builder_with_same_hits(ctx):
     for key in outs[0]:
         assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
     assert (outs[0]["node"] >= 0).sum() > 1000
+
+
+def test_scene_with_host_and_device_built_meshes(ctx):
+    """One scene holding one-leaf meshes (host, pair table), a host-built tree and two device-built trees (one of
+    them planar: the facing cull applies to it): tables of the device-built meshes sit behind the host-built ones.
+    Hits with PTK_OPT_DEVICE_KD = 2 (threshold), 1 (all on the GPU, the one-leaf meshes come back through the
+    download path) and 0 (all on the host) are the same, and equal to the oracle's on a sample."""
+    from oracle import oracle
+    from pathtracing_amd import _abi, scene as S
+    sc = S.Scene()
+    specs = [("plane", None), ("soup", random_soup(3000, 51)), ("big", random_soup(40_000, 52, extent=1.5)),
+             ("flat", None), ("cube", None)]
+    flat = random_soup(36_000, 53, extent=2.0)
+    flat[:, :, 1] = 0.0           # every vertex in the plane y = 0 ...
+    flat[:, :, 3:6] = [0.0, 1.0, 0.0]
+    a, b = flat[:, 1, 0:3] - flat[:, 0, 0:3], flat[:, 2, 0:3] - flat[:, 1, 0:3]
+    flip = np.cross(a, b)[:, 1] < 0  # ... and every face normal +y
+    flat[flip] = flat[flip][:, [0, 2, 1], :]
+    base = get_scene("room")
+    plane = next(n.shape for n in base.nodes if isinstance(n.shape, S.Mesh) and n.shape.triangles.shape[0] == 2)
+    cube = next(n.shape for n in base.nodes if isinstance(n.shape, S.Mesh) and n.shape.triangles.shape[0] == 12)
+    rng = np.random.default_rng(5)
+    for name, tris in specs:
+        node = S.SceneNode()
+        node.translate(rng.uniform(-1, 1, 3).astype(np.float32))
+        node.rotate(rng.normal(0, 1, 3).astype(np.float32), np.float32(rng.uniform(-2, 2)))
+        node.scale(rng.uniform(0.6, 1.4, 3).astype(np.float32))
+        node.shape = {"plane": plane, "cube": cube, "flat": S.Mesh(flat)}.get(name) or S.Mesh(tris)
+        sc.nodes.append(node)
+    o, d = random_rays(150_000, 23, -4, 4)
+    outs = []
+    try:
+        for mode in (2, 1, 0):
+            ctx.set_option(_abi.PTK_OPT_DEVICE_KD, mode)
+            ctx.upload(sc)
+            outs.append(ctx.intersect_batch(o, d))
+    finally:
+        ctx.set_option(_abi.PTK_OPT_DEVICE_KD, 2)
+    for other in outs[1:]:
+        for key in outs[0]:
+            assert np.array_equal(outs[0][key], other[key], equal_nan=True), key
+    hit_nodes = set(np.unique(outs[0]["node"]).tolist())
+    assert hit_nodes >= {0, 1, 2, 3, 4}
+    ora = oracle.OracleScene(sc)
+    ref = ora.intersect_batch(o[:20_000], d[:20_000])
+    assert np.array_equal(ref["node"], outs[0]["node"][:20_000]) and np.array_equal(ref["prim"], outs[0]["prim"][:20_000])

@@ -80,6 +80,38 @@ def test_room_matches_reference_png(gpu_ctx):
     assert abs(rgba[..., :3].mean() - ref[..., :3].mean()) < 0.5
 
 
+def test_mario_figure_matches_reference_png(gpu_ctx):
+    """The reference's other output: results/mario-128-i100.png (config 3: 128x128, 100 x 256 spp, KD-tree mesh
+    with the 2048^2 albedo texture, tonemapped 8-bit).  Same sample count on the GPU, same tone map.  That image
+    was rendered from an older mario.json: its room is deeper than the one res/scenes/mario.json describes today
+    (the back wall is smaller in it, the side walls longer), while the figure, the lamp and the camera are the
+    same.  So the comparison is restricted to the figure (its silhouette, texture mapping and shading: the
+    KD-tree path) and the lamp; the walls around it differ by 10-20 levels, as the scene does.  The texture is
+    decoded by PIL here and by stb_image there (a level of difference per texel at most)."""
+    from PIL import Image
+    import torch
+    gpu_ctx.upload(get_scene("mario"))
+    gpu_ctx.render_begin(128, 128, FOV)
+    img = gpu_ctx.render_image(seed=0, iterations=100, spi=256)
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(img).to(dev)
+    d_rgba = torch.empty(128 * 128, dtype=torch.int32, device=dev)
+    gpu_ctx.tonemap_dev(d_img.data_ptr(), d_rgba.data_ptr(), 128 * 128)
+    gpu_ctx.synchronize()
+    rgba = d_rgba.cpu().numpy().view(np.uint8).reshape(128, 128, 4)
+    ref = np.asarray(Image.open(f"{GOLDEN}/reference_results/mario-128-i100.png"))
+    assert ref.shape[:2] == (128, 128)
+    blk = lambda a: a[..., :3].astype(np.float64).reshape(16, 8, 16, 8, 3).mean(axis=(1, 3))  # 8x8-pixel blocks
+    bdiff = blk(rgba) - blk(ref)
+    figure = bdiff[3:14, 7:9]    # cap to feet, the two block columns wholly inside the silhouette
+    lamp = bdiff[0:1, 6:10]
+    assert np.abs(figure).mean() < 1.0, np.abs(figure).mean()   # measured 0.3 levels
+    assert np.abs(figure).max() < 4.0, np.abs(figure).max()
+    assert np.abs(lamp).mean() < 1.0, np.abs(lamp).mean()       # measured 0.1 levels
+    # and the part that must differ does: the walls beside the figure (guards against comparing the wrong file)
+    assert np.abs(bdiff[3:9, 2:4]).mean() > 5.0
+
+
 def test_deterministic_and_partition_invariant(gpu_ctx):
     """Same seed -> bitwise identical image; splitting the pixel range is bitwise neutral;
     splitting the sample range changes only the order of the per-pixel sum."""

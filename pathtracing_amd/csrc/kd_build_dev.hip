@@ -7,9 +7,9 @@
 //
 //   k_split_value  one wave per node: the split is the fp32 running sum of all 3n vertex coordinates
 //                  of the node's triangles IN ORDER, divided by float(3n) (scene.cpp:240-249).  fp32
-//                  addition does not reassociate, so the chain stays sequential: the wave stages 256
-//                  values at a time in LDS (coalesced loads, next block prefetched), then every lane
-//                  reads the same 16 bytes (LDS broadcast), sixteen reads ahead of the adds: ~4 cycles per value.
+//                  addition does not reassociate, so the chain stays sequential: the wave loads 256
+//                  values at a time (coalesced, next block prefetched) and adds them in order straight
+//                  from the registers, through DPP row shifts (chain_64): about 1.3 instructions per value.
 //                  Only the top few levels have chains long enough to matter (15 M adds at the root of
 //                  a 5 M-triangle mesh); below that thousands of chains run side by side.
 //   k_classify     one thread per (node, triangle) entry: left if any vertex <= split, right if any
@@ -105,13 +105,6 @@ struct QuadAdd {
     }
 };
 
-__device__ __forceinline__ void wave_sync_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ---- root: positions, bounds, level 0 ---------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_positions(const ptk_triangle* __restrict__ tris, uint32_t n, float* __restrict__ pos)
@@ -189,14 +182,48 @@ __global__ void k_root_node(uint32_t n, const Box* __restrict__ box, uint32_t* _
 
 // ---- one level ------------------------------------------------------------------------------------------
 
+// One step of the sequential sum over the 64 values a wave holds one per lane (lane l = value l).
+// Lane 15 of each 16-lane row adds its row's values in order: DPP row_shr:n lets lane 15 read lane
+// 15 - n, and the shifted copies do not depend on the running sum (the compiler makes the fifteen of
+// them once per register and reuses them for all four rows), so the chain itself is one v_add_f32 per
+// value.  row_bcast:15 hands the sum to the next row, readlane 63 to the next register.  Other lanes
+// compute values nobody reads.
+template <int N> __device__ __forceinline__ float dpp_row_shr(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + N, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float chain_row(float acc, float x)
+{
+    acc += dpp_row_shr<15>(x); acc += dpp_row_shr<14>(x); acc += dpp_row_shr<13>(x); acc += dpp_row_shr<12>(x);
+    acc += dpp_row_shr<11>(x); acc += dpp_row_shr<10>(x); acc += dpp_row_shr<9>(x);  acc += dpp_row_shr<8>(x);
+    acc += dpp_row_shr<7>(x);  acc += dpp_row_shr<6>(x);  acc += dpp_row_shr<5>(x);  acc += dpp_row_shr<4>(x);
+    acc += dpp_row_shr<3>(x);  acc += dpp_row_shr<2>(x);  acc += dpp_row_shr<1>(x);  acc += x;
+    return acc;
+}
+template <int ROW_MASK> __device__ __forceinline__ float chain_next_row(float acc)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, acc),
+                                                                 0x142 /* row_bcast:15 */, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float chain_64(float acc, float x)
+{
+    acc = chain_row(acc, x); // lane 15
+    acc = chain_next_row<0x2>(acc);
+    acc = chain_row(acc, x); // lane 31
+    acc = chain_next_row<0x4>(acc);
+    acc = chain_row(acc, x); // lane 47
+    acc = chain_next_row<0x8>(acc);
+    acc = chain_row(acc, x); // lane 63
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
+}
+
 __global__ __launch_bounds__(256) void k_split_value(uint32_t K, const uint32_t* __restrict__ start, const uint32_t* __restrict__ count,
                                                      const float* __restrict__ val, uint32_t depth, float* __restrict__ med,
                                                      uint32_t* __restrict__ stop)
 {
-    __shared__ __attribute__((aligned(16))) float buf[4][256];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * 4u + wave;
-    if (k >= K) return; // whole waves leave; no workgroup barrier below
+    if (k >= K) return;
     const uint32_t n = count[k];
     if (n <= 1u || depth == PTK_KD_MAX_DEPTH) { // scene.cpp:220
         if (lane == 0u) {
@@ -207,43 +234,28 @@ __global__ __launch_bounds__(256) void k_split_value(uint32_t K, const uint32_t*
     }
     const float* __restrict__ v = val + 3ull * start[k];
     const uint64_t total = 3ull * n;
-    float* b = buf[wave];
     float acc = 0.0f;
     // Values past the end read as +0: acc is never -0 (it starts at +0 and x + (-x) = +0), so acc + 0 = acc.
-    float x0 = (lane < total) ? v[lane] : 0.0f;
-    float x1 = (64u + lane < total) ? v[64u + lane] : 0.0f;
-    float x2 = (128u + lane < total) ? v[128u + lane] : 0.0f;
-    float x3 = (192u + lane < total) ? v[192u + lane] : 0.0f;
+    // The loads are unconditional (clamped index, then a select): with branches around them the compiler
+    // cannot count them and waits for the prefetch as well.
+    const uint64_t last = total - 1u;
+    auto fetch = [&](uint64_t i) {
+        const float t = v[i < total ? i : last];
+        return i < total ? t : 0.0f;
+    };
+    float x0 = fetch(lane), x1 = fetch(64u + lane), x2 = fetch(128u + lane), x3 = fetch(192u + lane);
     for (uint64_t base = 0; base < total; base += 256u) {
-        b[lane] = x0;
-        b[64u + lane] = x1;
-        b[128u + lane] = x2;
-        b[192u + lane] = x3;
-        const uint64_t nb = base + 256u;
-        x0 = (nb + lane < total) ? v[nb + lane] : 0.0f;
-        x1 = (nb + 64u + lane < total) ? v[nb + 64u + lane] : 0.0f;
-        x2 = (nb + 128u + lane < total) ? v[nb + 128u + lane] : 0.0f;
-        x3 = (nb + 192u + lane < total) ? v[nb + 192u + lane] : 0.0f;
-        wave_sync_lds();
-        // 64 values at a time: sixteen 16-byte reads (the same address in every lane: LDS broadcast) are
-        // in flight before the first add, so the chain runs at the VALU's pace.  The block's unused tail
-        // holds +0.
+        const float c0 = x0, c1 = x1, c2 = x2, c3 = x3;
+        const uint64_t nb = base + 256u; // the next block is on its way while this one is added
+        x0 = fetch(nb + lane);
+        x1 = fetch(nb + 64u + lane);
+        x2 = fetch(nb + 128u + lane);
+        x3 = fetch(nb + 192u + lane);
         const uint64_t left = total - base;
-        const uint32_t groups = left >= 256u ? 4u : (uint32_t)((left + 63u) >> 6);
-        const float4* q4 = reinterpret_cast<const float4*>(b);
-        for (uint32_t g = 0; g < groups; ++g) {
-            float4 t[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t[q] = q4[g * 16u + q];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                acc += t[q].x;
-                acc += t[q].y;
-                acc += t[q].z;
-                acc += t[q].w;
-            }
-        }
-        wave_sync_lds();
+        acc = chain_64(acc, c0);
+        if (left > 64u) acc = chain_64(acc, c1);
+        if (left > 128u) acc = chain_64(acc, c2);
+        if (left > 192u) acc = chain_64(acc, c3);
     }
     if (lane == 0u) {
         stop[k] = 0u;

@@ -180,7 +180,10 @@ def main():
                 keep.append(n)
         scene.nodes = keep
     ctx = Context(local_rank)
-    stream = torch.cuda.current_stream(dev)
+    # one explicit stream for everything: the kernels of the library, torch's own ops and the point RCCL
+    # orders its reduce against (torch.distributed synchronises with the current stream)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     if args.traversal is not None:
         ctx.set_option(1, args.traversal)

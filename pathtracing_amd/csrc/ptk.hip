@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
     }
 
     Hit h;
-    intersect_scene_mode<MODE>(S, o, d, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
+    intersect_scene_mode<MODE, FIRST>(S, o, d, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
 
     bool alive = false;
     if (on) alive = shade_ray(S, A, h, o, d, T, L, path);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_split(const DScene S, const D
 
     Hit h;
     unsigned long long trees;
-    intersect_scene_balanced<true, true>(S, o, d, on, h, wave_lds[tid >> 6], trees);
+    intersect_scene_balanced<true, true, FIRST>(S, o, d, on, h, wave_lds[tid >> 6], trees);
 
     const bool parked = on && trees != 0ull;
     // bounce 0 has no input queue: the walker reads the generated ray from queue 0

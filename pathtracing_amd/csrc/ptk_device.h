@@ -1006,7 +1006,9 @@ __device__ __forceinline__ void tri_eval2(const float4 r0, const float4 r1, cons
 
 // SPLIT: KD-tree nodes are not walked here; the ones that survive the cull are returned as a bit
 // mask over DScene::tree_nodes (at most 64 of them) for the walker kernel (k_walk in ptk.hip).
-template <bool PRUNE, bool SPLIT>
+// BUNDLE: the wave's rays are expected to be nearly the same ray (primary rays: a wave holds 64 samples
+// of one pixel), so the cull loop only visits the nodes that the bundle as a whole can touch (below).
+template <bool PRUNE, bool SPLIT, bool BUNDLE = false>
 __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best,
                                                          WaveLds& L, unsigned long long& tree_mask)
 {
@@ -1207,7 +1209,105 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
     const V3 noi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     const float o1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
     const bool sane = o1 + (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)) < 1e8f; // false on NaN
+    // Bundle pre-cull (BUNDLE): one test per node for the whole wave, 64 nodes at a time, lane = node.
+    // Take the first live lane's ray (oc, dc) as the central ray and let eo = max |o_i - oc|_1,
+    // ed = max |d_i - dc|_1 over the wave.  A ray i that reaches a point p of a node's padded world box
+    // does so at t_i <= |oc - c|_1 + eo + R (c the box centre, R its L1 half-extent), and the central
+    // ray's point at the same parameter is within eo + t_i ed of p.  So if ray i can touch the box, the
+    // central ray touches the box inflated by eo + T ed, T = |oc - c|_1 + eo + R: nodes failing that
+    // test cannot be hit by any ray of the wave and are skipped; the others still get the per-ray test.
+    // Incoherent waves just inflate every box until all nodes pass.
+    uint64_t bundle_mask = ~0ull; // candidate nodes among [bundle_base, bundle_base + 64)
+    uint32_t bundle_base = 0u;
+    V3 oc = o, dc = d;
+    float eo = 0.0f, ed = 0.0f;
+    bool bundle_sane = false;
+    if (BUNDLE) {
+        const uint64_t live = __builtin_amdgcn_ballot_w64(lane_on);
+        const int first = live ? (int)__builtin_ctzll(live) : 0;
+        oc = mk(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o.x), first)),
+                __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o.y), first)),
+                __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o.z), first)));
+        dc = mk(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d.x), first)),
+                __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d.y), first)),
+                __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d.z), first)));
+        const float my_eo = lane_on ? fabsf(o.x - oc.x) + fabsf(o.y - oc.y) + fabsf(o.z - oc.z) : 0.0f;
+        const float my_ed = lane_on ? fabsf(d.x - dc.x) + fabsf(d.y - dc.y) + fabsf(d.z - dc.z) : 0.0f;
+        // wave maxima through LDS (non-negative floats order like their bit patterns); NaN -> no pre-cull
+        const bool finite = !lane_on || (my_eo < 1e30f && my_ed < 1e30f);
+        L.compact[0] = 0u;
+        L.compact[1] = 0u;
+        wave_sync();
+        atomicMax(&L.compact[0], __float_as_uint(my_eo));
+        atomicMax(&L.compact[1], __float_as_uint(my_ed));
+        wave_sync();
+        eo = __uint_as_float(L.compact[0]);
+        ed = __uint_as_float(L.compact[1]);
+        bundle_sane = __builtin_amdgcn_ballot_w64(!(finite && sane)) == 0ull && live != 0ull;
+        wave_sync();
+    }
+    auto bundle_chunk = [&](uint32_t base) {
+        // lane = node base + lane: central ray against the inflated box, same slab formulation as below
+        const uint32_t nn = base + lane;
+        bool keep = nn < S.num_nodes;
+        if (bundle_sane && keep) {
+            const DCull cu = S.cull[nn];
+            const V3 invc = mk(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.x), -1e30f, 1e30f),
+                               __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.y), -1e30f, 1e30f),
+                               __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.z), -1e30f, 1e30f));
+            const float o1c = fabsf(oc.x) + fabsf(oc.y) + fabsf(oc.z) + eo;
+            const float m = __builtin_fmaf(cu.cull_k, o1c, cu.cull_c);
+            const float cx = 0.5f * (cu.bx[0] + cu.bx[1]), cy = 0.5f * (cu.by[0] + cu.by[1]), cz = 0.5f * (cu.bz[0] + cu.bz[1]);
+            const float R = 0.5f * ((cu.bx[1] - cu.bx[0]) + (cu.by[1] - cu.by[0]) + (cu.bz[1] - cu.bz[0])) + 3.0f * m;
+            const float T = fabsf(oc.x - cx) + fabsf(oc.y - cy) + fabsf(oc.z - cz) + eo + R;
+            const float g = 1.01f * (m + eo + T * ed) + 1e-30f; // total inflation, with slack for this arithmetic
+            const float tx0 = (cu.bx[0] - g - oc.x) * invc.x, tx1 = (cu.bx[1] + g - oc.x) * invc.x;
+            const float ty0 = (cu.by[0] - g - oc.y) * invc.y, ty1 = (cu.by[1] + g - oc.y) * invc.y;
+            const float tz0 = (cu.bz[0] - g - oc.z) * invc.z, tz1 = (cu.bz[1] + g - oc.z) * invc.z;
+            const float t_in = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+            const float t_out = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+            const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)); // false on NaN = keep
+            const bool finite_box = g < 1e30f;                                         // false on NaN / overflow = keep
+            keep = !(finite_box && (missed || t_out < 0.0f));
+        }
+        bundle_base = base;
+        bundle_mask = __builtin_amdgcn_ballot_w64(keep);
+    };
     uint32_t n = 0u;
+    if (BUNDLE) {
+        bundle_chunk(0u);
+        n = bundle_mask ? (uint32_t)__builtin_ctzll(bundle_mask) : 64u;
+    }
+    // BUNDLE: the next candidate node after n (walks the 64-node chunks)
+    auto advance = [&]() {
+        if (!BUNDLE) {
+            ++n;
+            return;
+        }
+        for (;;) {
+            const uint32_t bit = n - bundle_base + 1u; // bits above the current node
+            const uint64_t rest = bit < 64u ? (bundle_mask >> bit) << bit : 0ull;
+            if (rest != 0ull) {
+                n = bundle_base + (uint32_t)__builtin_ctzll(rest);
+                return;
+            }
+            if (bundle_base + 64u >= S.num_nodes) {
+                n = S.num_nodes;
+                return;
+            }
+            bundle_chunk(bundle_base + 64u);
+            if (bundle_mask & 1ull) {
+                n = bundle_base;
+                return;
+            }
+            n = bundle_base; // bit 0 is clear: look above it
+        }
+    };
+    if (BUNDLE && n >= 64u) { // no candidate in the first chunk
+        n = 0u;
+        bundle_mask &= ~1ull; // (it is 0 already) make advance() start above bit 0
+        advance();
+    }
     for (;;) {
         while (n < S.num_nodes && qtail - qhead < 64u) {
             // constant address space: the record comes in through scalar loads even though the
@@ -1227,13 +1327,13 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             const bool keep = lane_on && !(sane && (missed || t_out < 0.0f || facing_away));
             if (SPLIT && cu->cls == kClassTree) { // wave-uniform branch
                 tree_mask |= keep ? (1ull << (cu->tree_slot & 63u)) : 0ull;
-                ++n;
+                advance();
                 continue;
             }
             const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
             if (keep) L.queue[(qtail + mbcnt64(km)) & 127u] = (n << 6) | lane;
             qtail += (uint32_t)__popcll(km);
-            ++n;
+            advance();
         }
         const uint32_t qn = qtail - qhead;
         if (qn != 0u) process(qn < 64u ? qn : 64u);
@@ -1355,12 +1455,12 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
 // MODE bit 0: per-lane lists instead of the all-lanes-every-node loop (PTK_OPT_TRAVERSAL), bit 1: pruned KD
 // walk (PTK_OPT_KD_PRUNE), bit 2 (with bit 0): candidate lists after the conservative cull (PTK_OPT_NODE_CULL),
 // bit 3: wave-balanced work lists (PTK_OPT_BALANCE; needs the wave's WaveLds).
-template <int MODE>
+template <int MODE, bool BUNDLE = false>
 __device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best, WaveLds* L)
 {
     if (MODE & 8) {
         unsigned long long unused;
-        intersect_scene_balanced<(MODE & 2) != 0, false>(S, o, d, lane_on, best, *L, unused);
+        intersect_scene_balanced<(MODE & 2) != 0, false, BUNDLE>(S, o, d, lane_on, best, *L, unused);
     }
     else if ((MODE & 5) == 5) intersect_scene_lanelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
     else if (MODE & 1) intersect_scene_nodelist<(MODE & 2) != 0>(S, o, d, lane_on, best);

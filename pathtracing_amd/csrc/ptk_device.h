@@ -1512,6 +1512,18 @@ __device__ __forceinline__ V3 tex_pixel(const DTexture t, uint32_t x, uint32_t y
     return mk(p[0], p[1], p[2]);
 }
 
+// i % w for an index that is almost always below 2w (texel coordinates come from fract(u) * w, so they
+// are at most w): one compare-and-subtract instead of the ~25-instruction unsigned remainder; the general
+// remainder stays for whatever a non-finite uv turns into.
+__device__ __forceinline__ uint32_t wrap_index(uint32_t i, uint32_t w)
+{
+    if (i >= w) {
+        i -= w;
+        if (i >= w) i %= w;
+    }
+    return i;
+}
+
 // image::sample, sampler.cpp:36-61
 __device__ __forceinline__ V3 image_sample(const DTexture t, uint32_t mode, float u, float v)
 {
@@ -1520,16 +1532,16 @@ __device__ __forceinline__ V3 image_sample(const DTexture t, uint32_t mode, floa
     const float x = u0 * (float)t.w;
     const float y = v0 * (float)t.h;
     if (mode == PTK_MODE_LINEAR) {
-        const uint32_t x0 = (uint32_t)floorf(x) % t.w;
-        const uint32_t x1 = (uint32_t)ceilf(x) % t.w;
-        const uint32_t y0 = (uint32_t)floorf(y) % t.h;
-        const uint32_t y1 = (uint32_t)ceilf(y) % t.h;
+        const uint32_t x0 = wrap_index((uint32_t)floorf(x), t.w);
+        const uint32_t x1 = wrap_index((uint32_t)ceilf(x), t.w);
+        const uint32_t y0 = wrap_index((uint32_t)floorf(y), t.h);
+        const uint32_t y1 = wrap_index((uint32_t)ceilf(y), t.h);
         const V3 a = mix(tex_pixel(t, x0, y0), tex_pixel(t, x1, y0), x - (float)x0);
         const V3 b = mix(tex_pixel(t, x0, y1), tex_pixel(t, x1, y1), x - (float)x0);
         return mix(a, b, y - (float)y0);
     }
-    const uint32_t ix = (uint32_t)roundf(x) % t.w;
-    const uint32_t iy = (uint32_t)roundf(y) % t.h;
+    const uint32_t ix = wrap_index((uint32_t)roundf(x), t.w);
+    const uint32_t iy = wrap_index((uint32_t)roundf(y), t.h);
     return tex_pixel(t, ix, iy);
 }
 

@@ -196,6 +196,11 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
         if (tid == 0 && A.bounce + 1 < PTK_MAX_DEPTH) A.seg_count[(size_t)(A.bounce + 1) * A.num_segments + seg] = 0u;
         return;
     }
+    // A wave without a live ray leaves at once: its slot on the SIMD is free for another workgroup, and the
+    // barrier below only waits for the waves that are still running (the hardware counts the waves of the
+    // group that have not ended).  After bounce 0 of an open scene most segments are a quarter full.
+    const uint32_t live_waves = (cnt + 63u) / 64u;
+    if ((tid >> 6) >= live_waves) return;
     const bool on = tid < cnt;
     float* __restrict__ st = A.state;
     const uint64_t cap = A.cap;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
     uint32_t offset = 0, total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < kBlock / 64; ++w) {
-        const uint32_t c = wave_count[w];
+        const uint32_t c = (w < live_waves) ? wave_count[w] : 0u; // the waves that left wrote nothing
         offset += (w < wave) ? c : 0u;
         total += c;
     }

@@ -274,7 +274,7 @@ struct SplitBufs {
     float* q[2];                   // ray queues: kStateFields arrays of `cap` floats each, 256-slot segments
     uint32_t* seg_count;           // [PTK_MAX_DEPTH][num_segments] live rays of a segment entering bounce b
     uint32_t* seg_pend;            // [num_segments] parked rays of a segment (current bounce)
-    uint32_t* walk_head;           // [PTK_MAX_DEPTH] next segment chunk the walker hands out
+    uint32_t* walk_head;           // [PTK_MAX_DEPTH] next unit the walker hands out; [PTK_MAX_DEPTH + b]: units per grab (k_walk_plan)
     uint32_t* pend_slot;           // per parked ray (segment * 256 + i): its queue slot (render) / ray index (batch)
     unsigned long long* pend_mask; //   its tree nodes: bits over DScene::tree_nodes
     float* pend_best;              //   9 arrays of `cap`: d0, node, prim, a0..a2, pw of its best hit so far
@@ -426,6 +426,36 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch_split(const DScene S
 // be shaded).  Every pass of the outer loop makes progress: with fewer than 32 lanes walking there
 // are at least 33 lanes IDLE or DONE after the START/FIN step, so either 16 are IDLE (refill) or 17 are
 // DONE (shade); once the list is dry the walk loop runs the remaining lanes to the end.
+// How many units the walker takes per atomic, from what k_bounce_split parked.  Every grab is one atomic on
+// one address, about 8 ns each back to back: 65536 grabs are half a millisecond even when nearly nothing is
+// parked (an open scene after bounce 0).  With P parked rays the walker aims at ~96 rays per grab, but no
+// fewer than two grabs per wave and no more than the host's figure for full segments (base_chunk).
+__global__ __launch_bounds__(1024) void k_walk_plan(const uint32_t* __restrict__ seg_pend, uint32_t num_segments, uint32_t base_chunk,
+                                                   uint32_t waves, uint32_t* __restrict__ chunk_out)
+{
+    __shared__ unsigned long long part[16];
+    unsigned long long sum = 0ull;
+    for (uint32_t i = threadIdx.x; i < num_segments; i += 1024u) sum += seg_pend[i];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        unsigned long long parked = 0ull;
+        for (int w = 0; w < 16; ++w) parked += part[w];
+        const unsigned long long units = (unsigned long long)num_segments * 4ull;
+        const unsigned long long most = units / (base_chunk ? base_chunk : 1u); // grabs at the host's chunk
+        unsigned long long grabs = parked / 96ull;
+        if (grabs < 2ull * waves) grabs = 2ull * waves;
+        if (grabs > most) grabs = most;
+        if (grabs < 1ull) grabs = 1ull;
+        unsigned long long chunk = units / grabs;
+        if (chunk < base_chunk) chunk = base_chunk;
+        if (chunk >= 4ull) chunk &= ~3ull; // whole segments once a grab spans one
+        if (chunk < 1ull) chunk = 1ull;
+        *chunk_out = (uint32_t)(chunk > 0x40000000ull ? 0x40000000ull : chunk);
+    }
+}
+
 template <bool BATCH>
 __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32_t bounce_in, const SplitBufs Q, const BatchIO B)
 {
@@ -434,6 +464,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     const uint32_t lane = lane_id();
     const uint32_t bounce = BATCH ? 0u : bounce_in;
     const uint32_t nunits = Q.num_segments * 4u; // work units: quarters (64 slots) of the segments' parked lists
+    const uint32_t planned = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.walk_head[PTK_MAX_DEPTH + bounce]);
+    const uint32_t walk_chunk = planned ? planned : Q.walk_chunk; // k_walk_plan's figure for this bounce
     const uint64_t cap = Q.cap;
     const float* __restrict__ qin = Q.q[bounce & 1u];
 
@@ -465,20 +497,21 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
                 while (!dry && pos >= cnt) { // on to the next unit (a quarter of a segment's parked list) with rays
                     if (next_unit >= chunk_end) {
                         uint32_t base = 0u;
-                        if (lane == 0u) base = atomicAdd(Q.walk_head + bounce, Q.walk_chunk);
+                        if (lane == 0u) base = atomicAdd(Q.walk_head + bounce, walk_chunk);
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                         if (base >= nunits) {
                             dry = true;
                             break;
                         }
                         next_unit = base;
-                        chunk_end = base + Q.walk_chunk < nunits ? base + Q.walk_chunk : nunits;
+                        chunk_end = base + walk_chunk < nunits ? base + walk_chunk : nunits;
                     }
                     const uint32_t unit = next_unit++;
                     seg_cur = unit >> 2;
                     const uint32_t in_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.seg_pend[seg_cur]);
                     pos = (unit & 3u) * 64u;
                     cnt = in_seg < pos + 64u ? in_seg : pos + 64u;
+                    if (pos >= in_seg) next_unit = (unit | 3u) + 1u; // the segment's later quarters are empty too
                 }
                 if (dry) break;
                 const uint32_t avail = cnt - pos, left = (uint32_t)__popcll(idle_left);
@@ -1166,7 +1199,7 @@ bool split_mode(const ptk_ctx* c)
 }
 
 constexpr uint32_t kWalkBlocks = 1024; // persistent walker grid: 4 resident waves on each of the 1024 SIMDs
-constexpr uint32_t kSplitCounters = PTK_MAX_DEPTH;
+constexpr uint32_t kSplitCounters = 2 * PTK_MAX_DEPTH; // walk_head[bounce], then the walker's chunk per bounce (k_walk_plan)
 
 // Walker work units are quarter segments; small launches take them one at a time (short tail), large
 // ones in chunks so that the single head counter sees about 12 atomics per resident wave.
@@ -1681,6 +1714,7 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
         k_intersect_batch_split<<<g, b, 0, c->stream>>>(c->S, B, Q);
         const uint32_t wb = blocks < kWalkBlocks ? blocks : kWalkBlocks;
+        k_walk_plan<<<1, 1024, 0, c->stream>>>(Q.seg_pend, Q.num_segments, Q.walk_chunk, wb * (kBlock / 64), Q.walk_head + PTK_MAX_DEPTH);
         k_walk<true><<<dim3(wb), b, 0, c->stream>>>(c->S, 0u, Q, B);
         k_batch_parked<<<g, b, 0, c->stream>>>(c->S, B, Q);
     } else {
@@ -1858,6 +1892,8 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
                         if (b == 0) k_bounce_split<true><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
                         else k_bounce_split<false><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
                     }
+                    k_walk_plan<<<1, 1024, 0, c->stream>>>(Q.seg_pend, Q.num_segments, Q.walk_chunk, wb * (kBlock / 64),
+                                                            Q.walk_head + PTK_MAX_DEPTH + b);
                     {
                         LaunchTimer lt(c, PTK_KERNEL_WALK);
                         k_walk<false><<<dim3(wb), block, 0, c->stream>>>(c->S, b, Q, BatchIO{});

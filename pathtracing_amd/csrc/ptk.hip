@@ -1345,7 +1345,15 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
         const bool on_device = nt != 0 && (c->device_kd == 1 || (c->device_kd == 2 && nt >= kDeviceKdMinTriangles));
         if (on_device) {
             std::string msg;
-            if (int r = ptk_kd_build_device_keep(c->stream, sc->meshes[m].triangles, nt, nullptr, 0u, &dev.t[m], &msg)) return fail(c, r, msg);
+            if (int r = ptk_kd_build_device_keep(c->stream, sc->meshes[m].triangles, nt, nullptr, 0u, &dev.t[m], &msg)) {
+                dev.t[m].release();
+                // "auto" falls back to the host builder when the GPU build ran out of memory (its level buffers
+                // take ~60 B per (node, triangle) entry on top of the tables); an explicit 1 reports the error
+                if (r != PTK_ERR_NOMEM || c->device_kd != 2) return fail(c, r, msg);
+                (void)hipGetLastError();
+                ptk_kd_build_vectors(sc->meshes[m].triangles, nt, &c->kd_infos[m], built_nodes[m], built_prims[m]);
+                continue;
+            }
             c->kd_infos[m] = dev.t[m].info;
             if (dev.t[m].info.num_nodes <= 1u) { // a one-leaf mesh goes through the pair table: host path
                 if (int r = ptk_kd_tree_download(c->stream, dev.t[m], built_nodes[m], built_prims[m], &msg)) return fail(c, r, msg);

@@ -281,8 +281,9 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * trees of the parked rays, refilling lanes whose walk has ended; a third kernel shades the parked rays.
  * 0 = the KD walk stays inside the bounce kernel.  Same results either way.
  * PTK_OPT_DEVICE_KD: where ptk_scene_upload builds a mesh's KD-tree.  0 = host (ptk_kd_build's code),
- * 1 = GPU (ptk_kd_build_dev's code), 2 (default) = GPU for meshes of at least 32768 triangles.  The two
- * builders give byte-identical trees. */
+ * 1 = GPU (ptk_kd_build_dev's code), 2 (default) = GPU for meshes of at least 32768 triangles; with 2 a
+ * GPU build that runs out of device memory is redone by the host builder (1 reports the error).  The two
+ * builders give byte-identical trees; ray casting and shading never run on the host. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's

@@ -40,6 +40,43 @@ def test_image_matches_oracle_same_samples(gpu_ctx, name, w, h, spp):
     assert close.mean() > 0.98, close.mean()
 
 
+def test_many_nodes_primary_bundle_cull(gpu_ctx):
+    """150 nodes (spheres, cubes, planes, a small KD mesh): the bundle pre-cull of bounce 0 works through the
+    node table 64 nodes at a time (three chunks here), and with few samples per pixel a wave's bundle spans
+    several pixels.  Same samples as the oracle, which tests every node for every ray."""
+    from oracle import oracle
+    from conftest import random_soup
+    from pathtracing_amd import scene as S
+    rng = np.random.default_rng(31)
+    base = get_scene("room")
+    plane = next(n.shape for n in base.nodes if isinstance(n.shape, S.Mesh) and n.shape.triangles.shape[0] == 2)
+    cube = next(n.shape for n in base.nodes if isinstance(n.shape, S.Mesh) and n.shape.triangles.shape[0] == 12)
+    soup = S.Mesh(random_soup(600, 4, extent=1.0, size=0.25))
+    sc = S.Scene()
+    sc.camera.position = np.array([0.0, 0.0, 30.0], np.float32)
+    sc.camera.set_direction([0.0, 0.0, -1.0])
+    sc.background = S.ColorSampler([0.6, 0.7, 0.9])
+    for i in range(150):
+        node = S.SceneNode()
+        node.translate(np.array([rng.uniform(-11, 11), rng.uniform(-11, 11), rng.uniform(-25, 8)], np.float32))
+        node.rotate(rng.normal(0, 1, 3).astype(np.float32), np.float32(rng.uniform(0, 6.28)))
+        node.scale(rng.uniform(0.4, 1.6, 3).astype(np.float32))
+        node.shape = (S.Sphere(), cube, plane, soup)[i % 4] if i % 29 else soup
+        node.material.albedo = S.ColorSampler(rng.uniform(0.2, 0.9, 3).astype(np.float32))
+        if i % 11 == 0:
+            node.material.emission = S.ColorSampler([2.0, 1.5, 1.0])
+        sc.nodes.append(node)
+    ora = oracle.OracleScene(sc)
+    gpu_ctx.upload(sc)
+    for w, h, spi in ((40, 32, 3), (24, 24, 64)):
+        gpu_ctx.render_begin(w, h, FOV)
+        img = gpu_ctx.render_image(seed=7, iterations=2, spi=spi)
+        ref, _ = ora.render_image(w, h, FOV, 7, 2, spi, threads=8)
+        assert rel_mse(img, ref) < 1e-5, rel_mse(img, ref)
+        close = np.isclose(img, ref, rtol=2e-3, atol=2e-4).all(axis=2)
+        assert close.mean() > 0.97, close.mean()
+
+
 def test_furnace_known_answer(gpu_ctx):
     """furnace.json: E[L] = 0.18 on the sphere, exactly 1 on the background."""
     gpu_ctx.upload(get_scene("furnace"))

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch_split(const DScene S
 // DONE (shade); once the list is dry the walk loop runs the remaining lanes to the end.
 // How many units the walker takes per atomic, from what k_bounce_split parked.  Every grab is one atomic on
 // one address, about 8 ns each back to back: 65536 grabs are half a millisecond even when nearly nothing is
-// parked (an open scene after bounce 0).  With P parked rays the walker aims at ~96 rays per grab, but no
+// parked (an open scene after bounce 0).  With P parked rays the walker aims at ~48 rays per grab, but no
 // fewer than two grabs per wave and no more than the host's figure for full segments (base_chunk).
 __global__ __launch_bounds__(1024) void k_walk_plan(const uint32_t* __restrict__ seg_pend, uint32_t num_segments, uint32_t base_chunk,
                                                    uint32_t waves, uint32_t* __restrict__ chunk_out)
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_walk_plan(const uint32_t* __restrict__
         for (int w = 0; w < 16; ++w) parked += part[w];
         const unsigned long long units = (unsigned long long)num_segments * 4ull;
         const unsigned long long most = units / (base_chunk ? base_chunk : 1u); // grabs at the host's chunk
-        unsigned long long grabs = parked / 96ull;
+        unsigned long long grabs = parked / 48ull; // measured: 12-48 rays per grab are level, 96 and more lose to imbalance
         if (grabs < 2ull * waves) grabs = 2ull * waves;
         if (grabs > most) grabs = most;
         if (grabs < 1ull) grabs = 1ull;

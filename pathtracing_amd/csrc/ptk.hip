@@ -456,6 +456,15 @@ __global__ __launch_bounds__(1024) void k_walk_plan(const uint32_t* __restrict__
     }
 }
 
+#ifndef PTK_REFILL_IDLE
+#define PTK_REFILL_IDLE 24
+#endif
+#ifndef PTK_WALK_MIN
+#define PTK_WALK_MIN 28
+#endif
+constexpr uint32_t kRefillIdle = PTK_REFILL_IDLE; // idle lanes that trigger a refill
+constexpr uint32_t kWalkMin = PTK_WALK_MIN;       // walking lanes below which the walk loop yields to the refill
+
 template <bool BATCH>
 __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32_t bounce_in, const SplitBufs Q, const BatchIO B)
 {
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
         // refill
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == IDLE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
-        if (!dry && nidle >= 24u) {
+        if (!dry && nidle >= kRefillIdle) {
             uint64_t idle_left = idle;
             while (idle_left != 0ull) {
                 while (!dry && pos >= cnt) { // on to the next unit (a quarter of a segment's parked list) with rays
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
         // leaf (next: its triangles), or between nodes (next: a pop, which re-enters a node with six IEEE
         // divides).  Each pass serves the most populated place for all its lanes at once, so the pooled
         // leaf stage and the pops run for many lanes instead of being dragged along by every descend step.
-        const uint32_t walk_min = dry ? 1u : 28u;
+        const uint32_t walk_min = dry ? 1u : kWalkMin;
         for (;;) {
             if (state == WALK && W.cur == kWalkNone) state = FIN;
             const bool walking = state == WALK;

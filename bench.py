@@ -195,7 +195,10 @@ def main():
         ctx.set_option(4, args.balance)
     if args.split is not None:
         ctx.set_option(5, args.split)
+    t_up = time.perf_counter()
     ctx.upload(scene)
+    torch.cuda.synchronize(dev)
+    upload_ms = (time.perf_counter() - t_up) * 1e3  # scene flattening + KD build + tables to HBM, outside the timed steps
     ctx.render_begin(W, H, FOV)
     total = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
     image = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
@@ -251,7 +254,7 @@ def main():
             "mrays_per_s": rays / elapsed / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "scene_upload_ms": upload_ms,
             "config": {"workload": f"{WORKLOADS[args.workload]['desc']}; {W}x{H}, {SPI} spp per GPU per step "
                                    "(one CLI iteration per GPU), fov pi/4, depth 5",
                        "paths_per_step_per_gpu": W * H * SPI, "rays_per_path": rays / paths,

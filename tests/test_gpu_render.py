@@ -77,6 +77,34 @@ def test_many_nodes_primary_bundle_cull(gpu_ctx):
         assert close.mean() > 0.97, close.mean()
 
 
+@pytest.mark.parametrize("count", [0, 1, 63, 64, 65, 128, 129])
+def test_node_counts_around_the_bundle_chunk_size(gpu_ctx, count):
+    """Scenes of 0 .. 129 spheres, the last ones placed where the camera sees them: the primary-ray bundle
+    pre-cull walks the node table in chunks of 64, and a node in the second or third chunk must not be lost."""
+    from oracle import oracle
+    from pathtracing_amd import scene as S
+    sc = S.Scene()
+    sc.camera.position = np.array([0.0, 0.0, 12.0], np.float32)
+    sc.camera.set_direction([0.0, 0.0, -1.0])
+    sc.background = S.ColorSampler([0.5, 0.5, 0.5])
+    for i in range(count):
+        node = S.SceneNode()
+        last = i >= count - 2  # the last two nodes fill the view, the others sit outside it
+        node.translate(np.array([(-1.5 if i % 2 else 1.5) if last else 40.0 + i, 0.0 if last else 30.0, 0.0], np.float32))
+        node.scale(np.full(3, 1.4 if last else 0.5, np.float32))
+        node.shape = S.Sphere()
+        node.material.albedo = S.ColorSampler([0.9, 0.3, 0.2] if i % 2 else [0.2, 0.4, 0.9])
+        sc.nodes.append(node)
+    ora = oracle.OracleScene(sc)
+    gpu_ctx.upload(sc)
+    gpu_ctx.render_begin(24, 16, FOV)
+    img = gpu_ctx.render_image(seed=3, iterations=1, spi=32)
+    ref, _ = ora.render_image(24, 16, FOV, 3, 1, 32, threads=4)
+    assert rel_mse(img, ref) < 1e-5, rel_mse(img, ref)
+    if count:
+        assert np.abs(ref - 0.5).max() > 0.05  # the visible spheres are in the picture
+
+
 def test_furnace_known_answer(gpu_ctx):
     """furnace.json: E[L] = 0.18 on the sphere, exactly 1 on the background."""
     gpu_ctx.upload(get_scene("furnace"))

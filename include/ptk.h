@@ -274,7 +274,8 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * PTK_OPT_BALANCE: 1 = the (ray, node) pairs that survive the conservative cull, and the triangles
  * of the one-leaf meshes among them, are pooled per wave in LDS and dealt evenly to its 64 lanes
  * (overrides PTK_OPT_TRAVERSAL / PTK_OPT_NODE_CULL); 0 = off; 2 (default) = on for scenes with at
- * least two nodes.  Winners are chosen by the reference's own keys, so results do not change.
+ * least two nodes, except that bounces 1..4 of a scene with 16 or more nodes and no KD-tree use the per-lane
+ * candidate lists (PTK_OPT_TRAVERSAL / PTK_OPT_NODE_CULL at their defaults).  Winners are chosen by the reference's own keys, so results do not change.
  * PTK_OPT_SPLIT: scenes with KD-trees only (and PTK_OPT_KD_PRUNE, PTK_OPT_BALANCE on, at most 64 tree
  * nodes).  1 / 2 (default) = a bounce runs as two kernels: one casts every ray against the spheres and
  * one-leaf meshes and parks the rays that may hit a tree; a persistent walker kernel then walks the

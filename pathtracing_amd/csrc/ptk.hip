@@ -1192,7 +1192,11 @@ constexpr uint32_t kBalanceMinNodes = 2; // PTK_OPT_BALANCE = 2: pooled work lis
 constexpr uint32_t kCullMinNodes = 16; // PTK_OPT_NODE_CULL = 2: candidate lists from this many nodes on
 int kernel_mode(const ptk_ctx* c, bool primary)
 {
-    if (c->balance == 1 || (c->balance == 2 && c->S.num_nodes >= kBalanceMinNodes))
+    // "auto": the pooled work lists, except for the incoherent bounces of a scene of many analytic / one-leaf
+    // nodes, where the wave-uniform cull over every node costs more than per-lane candidate lists
+    // (materials.json, 25 spheres: k_bounce<false> 182 -> 171 us)
+    const bool many_flat_nodes = !primary && !c->deep_kd && c->S.num_nodes >= kCullMinNodes && c->traversal == 2 && c->node_cull == 2;
+    if (c->balance == 1 || (c->balance == 2 && c->S.num_nodes >= kBalanceMinNodes && !many_flat_nodes))
         return 8 | ((c->kd_prune && c->deep_kd) ? 2 : 0);
     const bool cull = c->node_cull == 1 || (c->node_cull == 2 && c->S.num_nodes >= kCullMinNodes);
     // PTK_OPT_TRAVERSAL = 2: primary rays walk every node together unless the cull pays off

@@ -48,15 +48,17 @@ def _gpu_ctx_session():
     ctx.close()
 
 
-@pytest.fixture(params=[(2, 1, 2, 1, 1), (2, 1, 2, 1, 0), (2, 1, 2, 0, 0), (1, 1, 1, 0, 0), (1, 1, 0, 0, 0), (0, 1, 2, 0, 0),
+@pytest.fixture(params=[(2, 1, 2, 2, 2), (2, 1, 2, 1, 1), (2, 1, 2, 1, 0), (2, 1, 2, 0, 0), (1, 1, 1, 0, 0), (1, 1, 0, 0, 0), (0, 1, 2, 0, 0),
                         (2, 0, 1, 0, 0), (2, 0, 2, 1, 0)],
-                ids=["split", "balanced", "lists-auto", "candidates", "nodelist", "uniform", "auto-refwalk-cull",
+                ids=["auto", "split", "balanced", "lists-auto", "candidates", "nodelist", "uniform", "auto-refwalk-cull",
                      "balanced-refwalk"])
 def gpu_ctx(request, _gpu_ctx_session):
     """One ptk context on cuda:0 for the whole GPU session (the HIP library must load: no fallback);
     every GPU test runs under every traversal mapping (PTK_OPT_SPLIT, PTK_OPT_BALANCE, PTK_OPT_TRAVERSAL x
     PTK_OPT_NODE_CULL) with the pruned KD walk, and with the reference-order KD walk (PTK_OPT_KD_PRUNE = 0).
-    "split" is the default configuration (the walker kernel runs wherever the scene has a KD-tree)."""
+    "auto" is the default configuration: every option left to the library (pooled lists, the walker kernel wherever
+    the scene has a KD-tree, per-lane lists for the later bounces of scenes with many flat nodes); "split" forces
+    the pooled lists and the walker."""
     from pathtracing_amd import _abi
     _gpu_ctx_session.set_option(_abi.PTK_OPT_TRAVERSAL, request.param[0])
     _gpu_ctx_session.set_option(_abi.PTK_OPT_KD_PRUNE, request.param[1])

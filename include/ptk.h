@@ -169,9 +169,17 @@ int ptk_ctx_synchronize(ptk_ctx* ctx);
  * Replaces scene::compile (scene.cpp:331-348) -> mesh::compile
  * (scene.cpp:123-140) -> kd_tree_node ctor (scene.cpp:214-286) and
  * triangle::update (scene.cpp:91-107): builds each mesh's KD-tree with the
- * reference's topology on the host, flattens it and uploads every table to HBM. */
+ * reference's topology (on the host for small meshes, on the GPU from 32768
+ * triangles on: PTK_OPT_DEVICE_KD; both give the same tree byte for byte),
+ * flattens it and uploads every table to HBM.  Invalidates the view: call
+ * ptk_render_begin again before rendering. */
 int ptk_scene_upload(ptk_ctx* ctx, const ptk_scene_desc* scene);
-/* Only the camera changed (Sandbox orbit camera, rtsb.cpp:295-299). */
+/* Only the camera changed (Sandbox orbit camera, rtsb.cpp:295-299): position and
+ * direction replace rt::scene::camera; scene tables, viewport, fov and ray queues
+ * stay, and the view basis of abstract_pathtracer.cpp:20-22 is rebuilt from the new
+ * direction, so the next ptk_render_samples_dev renders the new view (no
+ * ptk_render_begin needed if one was made before; work already enqueued on the
+ * stream keeps the old camera). */
 int ptk_scene_set_camera(ptk_ctx* ctx, const ptk_camera_desc* camera);
 
 /* Host-side KD build alone (no GPU needed): kd_tree_node ctor, scene.cpp:214-286.

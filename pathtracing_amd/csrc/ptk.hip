@@ -196,36 +196,39 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
         if (tid == 0 && A.bounce + 1 < PTK_MAX_DEPTH) A.seg_count[(size_t)(A.bounce + 1) * A.num_segments + seg] = 0u;
         return;
     }
-    // A wave without a live ray leaves at once: its slot on the SIMD is free for another workgroup, and the
-    // barrier below only waits for the waves that are still running (the hardware counts the waves of the
-    // group that have not ended).  After bounce 0 of an open scene most segments are a quarter full.
+    // A wave without a live ray skips the cast and the shading (a wave-uniform branch) but stays for the
+    // workgroup barrier of the compaction below: every wave of the group reaches it.  Occupancy is bounded by
+    // the workgroup's LDS, which is held until its last wave ends either way, so the idle wave costs nothing.
+    // After bounce 0 of an open scene most segments are a quarter full.
     const uint32_t live_waves = (cnt + 63u) / 64u;
-    if ((tid >> 6) >= live_waves) return;
+    const bool wave_live = (tid >> 6) < live_waves;
     const bool on = tid < cnt;
     float* __restrict__ st = A.state;
     const uint64_t cap = A.cap;
 
-    V3 o, d, T, L;
-    uint32_t path;
-    if (FIRST) {
-        path = slot;
-        primary_ray(S, V, A, path, o, d);
-        T = mk(1.0f, 1.0f, 1.0f);
-        L = mk(0.0f, 0.0f, 0.0f);
-    } else {
-        const uint32_t rs = on ? slot : seg * kBlock;
-        o = mk(st[0 * cap + rs], st[1 * cap + rs], st[2 * cap + rs]);
-        d = mk(st[3 * cap + rs], st[4 * cap + rs], st[5 * cap + rs]);
-        T = mk(st[6 * cap + rs], st[7 * cap + rs], st[8 * cap + rs]);
-        L = mk(st[9 * cap + rs], st[10 * cap + rs], st[11 * cap + rs]);
-        path = __float_as_uint(st[12 * cap + rs]);
-    }
-
-    Hit h;
-    intersect_scene_mode<MODE, FIRST>(S, o, d, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
-
+    V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f), T = o, L = o;
+    uint32_t path = 0u;
     bool alive = false;
-    if (on) alive = shade_ray(S, A, h, o, d, T, L, path);
+    if (wave_live) {
+        if (FIRST) {
+            path = slot;
+            primary_ray(S, V, A, path, o, d);
+            T = mk(1.0f, 1.0f, 1.0f);
+            L = mk(0.0f, 0.0f, 0.0f);
+        } else {
+            const uint32_t rs = on ? slot : seg * kBlock;
+            o = mk(st[0 * cap + rs], st[1 * cap + rs], st[2 * cap + rs]);
+            d = mk(st[3 * cap + rs], st[4 * cap + rs], st[5 * cap + rs]);
+            T = mk(st[6 * cap + rs], st[7 * cap + rs], st[8 * cap + rs]);
+            L = mk(st[9 * cap + rs], st[10 * cap + rs], st[11 * cap + rs]);
+            path = __float_as_uint(st[12 * cap + rs]);
+        }
+
+        Hit h;
+        intersect_scene_mode<MODE, FIRST>(S, o, d, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
+
+        if (on) alive = shade_ray(S, A, h, o, d, T, L, path);
+    }
 
     PTK_STAT(S, 12, PTK_CLOCK() - kc0);
     if (A.bounce + 1 >= PTK_MAX_DEPTH) return;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
     uint32_t offset = 0, total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < kBlock / 64; ++w) {
-        const uint32_t c = (w < live_waves) ? wave_count[w] : 0u; // the waves that left wrote nothing
+        const uint32_t c = wave_count[w]; // idle waves wrote 0
         offset += (w < wave) ? c : 0u;
         total += c;
     }
@@ -708,10 +711,10 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float* __restrict__
                                                        uint32_t num_pixels, uint32_t samples, uint64_t pixel_begin,
                                                        float* __restrict__ sum_rgb, int accumulate)
 {
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     if (wave >= num_pixels) return;
-    const uint64_t base = (uint64_t)wave * samples;
+    const uint64_t base = wave * samples;
     float r = 0.0f, g = 0.0f, b = 0.0f;
     for (uint32_t s = lane; s < samples; s += 64u) {
         r += sample_L[0 * cap + base + s];
@@ -804,6 +807,7 @@ struct ptk_ctx {
     // render state
     float cam_dir[3] = { 0.0f, 0.0f, -1.0f }; // rt::camera::m_direction (scene.h:36)
     DView V{};
+    float fov_y = 0.0f;
     bool has_view = false;
     uint64_t cap = 0;
     float* d_state = nullptr;
@@ -936,6 +940,23 @@ __host__ __device__ inline HV3 hnormalize(HV3 a)
     return { a.x * s, a.y * s, a.z * s };
 }
 
+// abstract_pathtracer.cpp:20-25 (host fp32, same operand order as the oracle)
+DView make_view(const float cam_dir[3], uint32_t width, uint32_t height, float fov_y)
+{
+    const HV3 fwd = hnormalize({ cam_dir[0], cam_dir[1], cam_dir[2] });
+    const HV3 right = hnormalize(hcross(fwd, { 0.0f, 1.0f, 0.0f }));
+    const HV3 up = hcross(right, fwd);
+    DView V{};
+    V.fx = fwd.x; V.fy = fwd.y; V.fz = fwd.z;
+    V.rx = right.x; V.ry = right.y; V.rz = right.z;
+    V.ux = up.x; V.uy = up.y; V.uz = up.z;
+    V.h2 = std::atan(fov_y / 2.0f);
+    V.w2 = V.h2 * (float)width / (float)height;
+    V.width = width;
+    V.height = height;
+    return V;
+}
+
 // triangle::update, scene.cpp:91-107 -> 64-B hit record
 __host__ __device__ void make_hit_record(const ptk_triangle& t, float4* q)
 {
@@ -958,6 +979,32 @@ __host__ __device__ void make_shade_record(const ptk_triangle& t, float4* s)
     s[1] = make_float4(t.v[1].normal[1], t.v[1].normal[2], t.v[2].normal[0], t.v[2].normal[1]);
     s[2] = make_float4(t.v[2].normal[2], t.v[0].uv[0], t.v[0].uv[1], t.v[1].uv[0]);
     s[3] = make_float4(t.v[1].uv[1], t.v[2].uv[0], t.v[2].uv[1], 0.0f);
+}
+
+// Children of interior node `n` (preorder index i) whose first child is `c` (index i + 1).  The builder makes a
+// child only for a non-empty side (scene.cpp:280-284), so the next preorder slot is the LEFT child when there is
+// one and the RIGHT child otherwise (every vertex above the split: the fp32 mean of scene.cpp:240-249 can round
+// below all of them, e.g. a planar cluster at x = 0.1f).  Child boxes are the parent's box with one plane moved to
+// the split (scene.cpp:31-56): the left child keeps the parent's min on the axis, the right child gets min = split.
+// So the slot holds a right-only child exactly when its min differs from the parent's (compared as bits; if they
+// are equal the two readings describe the same box and the same six quotients).  A right-only node is marked by
+// right == i + 1, which walk_descend_step reads as "no left child".
+__host__ __device__ inline uint32_t kd_f2u(float f)
+{
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    return v.u;
+}
+__host__ __device__ inline void kd_children(const ptk_kd_node& n, const ptk_kd_node& c, uint32_t i, uint32_t axis, DKdNode& k)
+{
+    const bool right_only = c.skip >= n.skip && kd_f2u(c.bmin[axis]) != kd_f2u(n.bmin[axis]);
+    if (right_only) {
+        k.right = i + 1u;
+        k.split = c.bmin[axis];
+    } else {
+        k.right = c.skip; // == n.skip (= k.a) when there is no right child
+        k.split = c.bmax[axis];
+    }
 }
 
 // ---- flattening of a tree that the GPU builder left in device memory (ptk_scene_upload) ----------
@@ -987,9 +1034,8 @@ __global__ __launch_bounds__(256) void k_flat_kd(const ptk_kd_node* __restrict__
     } else {
         k.a = n.skip;
         k.b_axis = axis << 30;
-        const bool has_left = i + 1 < count && i + 1 < n.skip;
-        k.right = has_left ? nodes[i + 1].skip : n.skip;
-        if (has_left) k.split = nodes[i + 1].bmax[axis];
+        k.right = n.skip;
+        if (i + 1 < count && i + 1 < n.skip) kd_children(n, nodes[i + 1], i, axis, k);
     }
     out[i] = k;
 }
@@ -1227,9 +1273,140 @@ uint32_t walk_chunk_for(uint32_t num_segments)
 
 constexpr uint64_t kDeviceKdMinTriangles = 32768; // PTK_OPT_DEVICE_KD = 2: meshes at least this large build on the GPU
 
+// The launch chain of ptk_render_samples_dev over the scratch buffers `R`
+// (the context's own allocations): chunks of at most R.cap paths, five bounces each.
+struct RenderBufs {
+    float* state;                 // queue 0: kStateFields arrays of `cap` floats
+    float* state2;                // queue 1 (split mode)
+    float* sample_L;              // 3 arrays of `cap` floats
+    uint32_t* seg_count;          // [PTK_MAX_DEPTH][cap / 256]
+    uint32_t* split_counters;     // [kSplitCounters]
+    uint32_t* seg_pend;           // [cap / 256]
+    uint32_t* pend_slot;          // [cap]
+    unsigned long long* pend_mask; // [cap]
+    float* pend_best;             // 9 arrays of `cap` floats
+    uint64_t cap;
+};
+
 int set_device(ptk_ctx* c)
 {
     PTK_HIP(c, hipSetDevice(c->device));
+    return PTK_OK;
+}
+
+// (RenderBufs above) the launch chain itself
+int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t pixel_begin, uint64_t pixel_count,
+                        uint64_t sample_begin, uint32_t sample_count, float* sum_rgb, int accumulate)
+{
+    const uint64_t cap = R.cap;
+    const bool split = split_mode(c);
+    const uint32_t s_chunk = (uint32_t)((uint64_t)sample_count < cap ? sample_count : cap);
+    const uint64_t p_chunk = cap / s_chunk;
+    for (uint32_t s0 = 0; s0 < sample_count; s0 += s_chunk) {
+        const uint32_t ns = (sample_count - s0 < s_chunk) ? sample_count - s0 : s_chunk;
+        const int acc = (accumulate || s0 > 0) ? 1 : 0;
+        for (uint64_t p0 = 0; p0 < pixel_count; p0 += p_chunk) {
+            const uint64_t np = (pixel_count - p0 < p_chunk) ? pixel_count - p0 : p_chunk;
+            const uint64_t n_paths = np * ns; // <= cap < 2^31
+            BounceArgs A{};
+            A.state = R.state;
+            A.sample_L = R.sample_L;
+            A.seg_count = R.seg_count;
+            A.cap = cap;
+            A.num_segments = (uint32_t)((n_paths + kBlock - 1) / kBlock);
+            A.n_paths = (uint32_t)n_paths;
+            A.samples = ns;
+            A.pixel_begin = pixel_begin + p0;
+            A.sample_begin = sample_begin + s0;
+            A.seed = seed;
+            A.bounce = 0;
+            const dim3 grid(A.num_segments), block(kBlock);
+            if (split) {
+                PTK_HIP(c, hipMemsetAsync(R.split_counters, 0, kSplitCounters * sizeof(uint32_t), c->stream));
+                SplitBufs Q{};
+                Q.q[0] = R.state;
+                Q.q[1] = R.state2;
+                Q.seg_count = R.seg_count;
+                Q.seg_pend = R.seg_pend;
+                Q.walk_head = R.split_counters;
+                Q.num_segments = A.num_segments;
+                Q.walk_chunk = walk_chunk_for(A.num_segments);
+                Q.pend_slot = R.pend_slot;
+                Q.pend_mask = R.pend_mask;
+                Q.pend_best = R.pend_best;
+                Q.cap = cap;
+                const uint32_t wb = A.num_segments < kWalkBlocks ? A.num_segments : kWalkBlocks;
+                for (uint32_t b = 0; b < PTK_MAX_DEPTH; ++b) {
+                    A.bounce = b;
+                    {
+                        LaunchTimer lt(c, b == 0 ? PTK_KERNEL_BOUNCE_FIRST : PTK_KERNEL_BOUNCE_NEXT);
+                        if (b == 0) k_bounce_split<true><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
+                        else k_bounce_split<false><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
+                    }
+                    k_walk_plan<<<1, 1024, 0, c->stream>>>(Q.seg_pend, Q.num_segments, Q.walk_chunk, wb * (kBlock / 64),
+                                                            Q.walk_head + PTK_MAX_DEPTH + b);
+                    {
+                        LaunchTimer lt(c, PTK_KERNEL_WALK);
+                        k_walk<false><<<dim3(wb), block, 0, c->stream>>>(c->S, b, Q, BatchIO{});
+                    }
+                    LaunchTimer lt(c, PTK_KERNEL_SHADE_PARKED);
+                    k_shade_parked<<<grid, block, 0, c->stream>>>(c->S, A, Q);
+                }
+                const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
+                {
+                    LaunchTimer lt(c, PTK_KERNEL_ACCUMULATE);
+                    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, R.sample_L, cap,
+                                       (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
+                }
+                const uint32_t entries = A.num_segments * (PTK_MAX_DEPTH - 1);
+                const uint32_t tally_blocks = entries / (kBlock * 8) + 1 > 256u ? 256u : entries / (kBlock * 8) + 1;
+                hipLaunchKernelGGL(k_tally, dim3(tally_blocks), dim3(kBlock), 0, c->stream,
+                                   R.seg_count + A.num_segments, entries, (uint32_t)n_paths, c->d_counters);
+                PTK_HIP(c, hipGetLastError());
+                continue;
+            }
+#define PTK_BOUNCE(F, M) k_bounce<F, M><<<grid, block, 0, c->stream>>>(c->S, c->V, A)
+            {
+                LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
+                switch (kernel_mode(c, true)) {
+                case 0: PTK_BOUNCE(true, 0); break;
+                case 1: PTK_BOUNCE(true, 1); break;
+                case 2: PTK_BOUNCE(true, 2); break;
+                case 3: PTK_BOUNCE(true, 3); break;
+                case 5: PTK_BOUNCE(true, 5); break;
+                case 7: PTK_BOUNCE(true, 7); break;
+                case 8: PTK_BOUNCE(true, 8); break;
+                default: PTK_BOUNCE(true, 10); break;
+                }
+            }
+            for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) {
+                A.bounce = b;
+                LaunchTimer lt(c, PTK_KERNEL_BOUNCE_NEXT);
+                switch (kernel_mode(c, false)) {
+                case 0: PTK_BOUNCE(false, 0); break;
+                case 1: PTK_BOUNCE(false, 1); break;
+                case 2: PTK_BOUNCE(false, 2); break;
+                case 3: PTK_BOUNCE(false, 3); break;
+                case 5: PTK_BOUNCE(false, 5); break;
+                case 7: PTK_BOUNCE(false, 7); break;
+                case 8: PTK_BOUNCE(false, 8); break;
+                default: PTK_BOUNCE(false, 10); break;
+                }
+            }
+#undef PTK_BOUNCE
+            const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
+            {
+                LaunchTimer lt(c, PTK_KERNEL_ACCUMULATE);
+                hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, R.sample_L, cap,
+                                   (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
+            }
+            const uint32_t entries = A.num_segments * (PTK_MAX_DEPTH - 1);
+            const uint32_t tally_blocks = entries / (kBlock * 8) + 1 > 256u ? 256u : entries / (kBlock * 8) + 1;
+            hipLaunchKernelGGL(k_tally, dim3(tally_blocks), dim3(kBlock), 0, c->stream,
+                               R.seg_count + A.num_segments, entries, (uint32_t)n_paths, c->d_counters);
+            PTK_HIP(c, hipGetLastError());
+        }
+    }
     return PTK_OK;
 }
 
@@ -1441,11 +1618,8 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
             } else {
                 k.a = n.skip;
                 k.b_axis = axis << 30;
-                // left child = next preorder slot (its box is this box cut at `split` from above,
-                // scene.cpp:31-56); the right child starts where the left subtree ends
-                const bool has_left = i + 1 < nodes.size() && i + 1 < n.skip;
-                k.right = has_left ? nodes[i + 1].skip : n.skip;
-                if (has_left) k.split = nodes[i + 1].bmax[axis];
+                k.right = n.skip;
+                if (i + 1 < nodes.size() && i + 1 < n.skip) kd_children(n, nodes[i + 1], (uint32_t)i, axis, k);
             }
             kd.push_back(k);
         }
@@ -1685,7 +1859,8 @@ int ptk_scene_set_camera(ptk_ctx* c, const ptk_camera_desc* cam)
     c->S.cam_y = cam->position[1];
     c->S.cam_z = cam->position[2];
     std::memcpy(c->cam_dir, cam->direction, sizeof(c->cam_dir));
-    c->has_view = false; // ptk_render_begin must be called again
+    // the view basis follows the camera (abstract_pathtracer.cpp:20-22); viewport, fov and queues stay
+    if (c->has_view) c->V = make_view(c->cam_dir, c->V.width, c->V.height, c->fov_y);
     return PTK_OK;
 }
 
@@ -1817,18 +1992,7 @@ int ptk_render_begin(ptk_ctx* c, uint32_t width, uint32_t height, float fov_y, u
     if (max_paths > 0x7FFFFF00ull) max_paths = 0x7FFFFF00ull;
     const uint64_t cap = (max_paths + kBlock - 1) / kBlock * kBlock;
 
-    // abstract_pathtracer.cpp:20-25 (host fp32, same operand order as the oracle)
-    const HV3 fwd = hnormalize({ c->cam_dir[0], c->cam_dir[1], c->cam_dir[2] });
-    const HV3 right = hnormalize(hcross(fwd, { 0.0f, 1.0f, 0.0f }));
-    const HV3 up = hcross(right, fwd);
-    DView V{};
-    V.fx = fwd.x; V.fy = fwd.y; V.fz = fwd.z;
-    V.rx = right.x; V.ry = right.y; V.rz = right.z;
-    V.ux = up.x; V.uy = up.y; V.uz = up.z;
-    V.h2 = std::atan(fov_y / 2.0f);
-    V.w2 = V.h2 * (float)width / (float)height;
-    V.width = width;
-    V.height = height;
+    const DView V = make_view(c->cam_dir, width, height, fov_y);
 
     if (cap != c->cap) {
         PTK_HIP(c, hipStreamSynchronize(c->stream));
@@ -1839,6 +2003,7 @@ int ptk_render_begin(ptk_ctx* c, uint32_t width, uint32_t height, float fov_y, u
         c->cap = cap;
     }
     c->V = V;
+    c->fov_y = fov_y;
     c->has_view = true;
     return PTK_OK;
 }
@@ -1858,8 +2023,8 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
         if (!accumulate) PTK_HIP(c, hipMemsetAsync(sum_rgb + pixel_begin * 3, 0, pixel_count * 3 * sizeof(float), c->stream));
         return PTK_OK;
     }
-    const uint64_t cap = c->cap;
     const bool split = split_mode(c);
+    const uint64_t cap = c->cap;
     if (split && c->split_cap != cap) {
         PTK_HIP(c, hipStreamSynchronize(c->stream));
         free_split(c);
@@ -1871,114 +2036,18 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
         PTK_HIP(c, hipMalloc((void**)&c->d_pend_best, cap * 9 * sizeof(float)));
         c->split_cap = cap;
     }
-    const uint32_t s_chunk = (uint32_t)((uint64_t)sample_count < cap ? sample_count : cap);
-    const uint64_t p_chunk = cap / s_chunk;
-    for (uint32_t s0 = 0; s0 < sample_count; s0 += s_chunk) {
-        const uint32_t ns = (sample_count - s0 < s_chunk) ? sample_count - s0 : s_chunk;
-        const int acc = (accumulate || s0 > 0) ? 1 : 0;
-        for (uint64_t p0 = 0; p0 < pixel_count; p0 += p_chunk) {
-            const uint64_t np = (pixel_count - p0 < p_chunk) ? pixel_count - p0 : p_chunk;
-            const uint64_t n_paths = np * ns; // <= cap < 2^31
-            BounceArgs A{};
-            A.state = c->d_state;
-            A.sample_L = c->d_sample_L;
-            A.seg_count = c->d_seg_count;
-            A.cap = cap;
-            A.num_segments = (uint32_t)((n_paths + kBlock - 1) / kBlock);
-            A.n_paths = (uint32_t)n_paths;
-            A.samples = ns;
-            A.pixel_begin = pixel_begin + p0;
-            A.sample_begin = sample_begin + s0;
-            A.seed = seed;
-            A.bounce = 0;
-            const dim3 grid(A.num_segments), block(kBlock);
-            if (split) {
-                PTK_HIP(c, hipMemsetAsync(c->d_split_counters, 0, kSplitCounters * sizeof(uint32_t), c->stream));
-                SplitBufs Q{};
-                Q.q[0] = c->d_state;
-                Q.q[1] = c->d_state2;
-                Q.seg_count = c->d_seg_count;
-                Q.seg_pend = c->d_seg_pend;
-                Q.walk_head = c->d_split_counters;
-                Q.num_segments = A.num_segments;
-                Q.walk_chunk = walk_chunk_for(A.num_segments);
-                Q.pend_slot = c->d_pend_slot;
-                Q.pend_mask = c->d_pend_mask;
-                Q.pend_best = c->d_pend_best;
-                Q.cap = cap;
-                const uint32_t wb = A.num_segments < kWalkBlocks ? A.num_segments : kWalkBlocks;
-                for (uint32_t b = 0; b < PTK_MAX_DEPTH; ++b) {
-                    A.bounce = b;
-                    {
-                        LaunchTimer lt(c, b == 0 ? PTK_KERNEL_BOUNCE_FIRST : PTK_KERNEL_BOUNCE_NEXT);
-                        if (b == 0) k_bounce_split<true><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
-                        else k_bounce_split<false><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
-                    }
-                    k_walk_plan<<<1, 1024, 0, c->stream>>>(Q.seg_pend, Q.num_segments, Q.walk_chunk, wb * (kBlock / 64),
-                                                            Q.walk_head + PTK_MAX_DEPTH + b);
-                    {
-                        LaunchTimer lt(c, PTK_KERNEL_WALK);
-                        k_walk<false><<<dim3(wb), block, 0, c->stream>>>(c->S, b, Q, BatchIO{});
-                    }
-                    LaunchTimer lt(c, PTK_KERNEL_SHADE_PARKED);
-                    k_shade_parked<<<grid, block, 0, c->stream>>>(c->S, A, Q);
-                }
-                const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
-                {
-                    LaunchTimer lt(c, PTK_KERNEL_ACCUMULATE);
-                    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, c->d_sample_L, cap,
-                                       (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
-                }
-                const uint32_t entries = A.num_segments * (PTK_MAX_DEPTH - 1);
-                const uint32_t tally_blocks = entries / (kBlock * 8) + 1 > 256u ? 256u : entries / (kBlock * 8) + 1;
-                hipLaunchKernelGGL(k_tally, dim3(tally_blocks), dim3(kBlock), 0, c->stream,
-                                   c->d_seg_count + A.num_segments, entries, (uint32_t)n_paths, c->d_counters);
-                PTK_HIP(c, hipGetLastError());
-                continue;
-            }
-#define PTK_BOUNCE(F, M) k_bounce<F, M><<<grid, block, 0, c->stream>>>(c->S, c->V, A)
-            {
-                LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
-                switch (kernel_mode(c, true)) {
-                case 0: PTK_BOUNCE(true, 0); break;
-                case 1: PTK_BOUNCE(true, 1); break;
-                case 2: PTK_BOUNCE(true, 2); break;
-                case 3: PTK_BOUNCE(true, 3); break;
-                case 5: PTK_BOUNCE(true, 5); break;
-                case 7: PTK_BOUNCE(true, 7); break;
-                case 8: PTK_BOUNCE(true, 8); break;
-                default: PTK_BOUNCE(true, 10); break;
-                }
-            }
-            for (uint32_t b = 1; b < PTK_MAX_DEPTH; ++b) {
-                A.bounce = b;
-                LaunchTimer lt(c, PTK_KERNEL_BOUNCE_NEXT);
-                switch (kernel_mode(c, false)) {
-                case 0: PTK_BOUNCE(false, 0); break;
-                case 1: PTK_BOUNCE(false, 1); break;
-                case 2: PTK_BOUNCE(false, 2); break;
-                case 3: PTK_BOUNCE(false, 3); break;
-                case 5: PTK_BOUNCE(false, 5); break;
-                case 7: PTK_BOUNCE(false, 7); break;
-                case 8: PTK_BOUNCE(false, 8); break;
-                default: PTK_BOUNCE(false, 10); break;
-                }
-            }
-#undef PTK_BOUNCE
-            const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
-            {
-                LaunchTimer lt(c, PTK_KERNEL_ACCUMULATE);
-                hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, c->d_sample_L, cap,
-                                   (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
-            }
-            const uint32_t entries = A.num_segments * (PTK_MAX_DEPTH - 1);
-            const uint32_t tally_blocks = entries / (kBlock * 8) + 1 > 256u ? 256u : entries / (kBlock * 8) + 1;
-            hipLaunchKernelGGL(k_tally, dim3(tally_blocks), dim3(kBlock), 0, c->stream,
-                               c->d_seg_count + A.num_segments, entries, (uint32_t)n_paths, c->d_counters);
-            PTK_HIP(c, hipGetLastError());
-        }
-    }
-    return PTK_OK;
+    RenderBufs R{};
+    R.state = c->d_state;
+    R.state2 = c->d_state2;
+    R.sample_L = c->d_sample_L;
+    R.seg_count = c->d_seg_count;
+    R.split_counters = c->d_split_counters;
+    R.seg_pend = c->d_seg_pend;
+    R.pend_slot = c->d_pend_slot;
+    R.pend_mask = c->d_pend_mask;
+    R.pend_best = c->d_pend_best;
+    R.cap = cap;
+    return render_samples_impl(c, R, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb, accumulate);
 }
 
 int ptk_resolve_iteration_dev(ptk_ctx* c, const float* sum_rgb, float* image_rgb, uint64_t spi, uint64_t iteration)

@@ -54,7 +54,8 @@ static_assert(sizeof(DNode) == 256, "DNode must be 256 B");
 // Flattened KD node, 64 B = four 16-B words:
 //   h = { a, b | axis<<30, right, split }   header
 //        interior: a = skip index (first node after the subtree), b = 0, right = index of
-//                  the right child (the left child is the next slot), split = the plane the
+//                  the right child (the left child is the next slot; right == own index + 1 means
+//                  there is no left child, right == a no right child), split = the plane the
 //                  node's box is cut at (scene.cpp:240-251), axis = depth % 3
 //        leaf:     a = first leaf-ordered primitive, b = primitive count (> 0)
 //   x = { cmin.x, cmin.y, cmin.z, cmax.x }   c* = the reference's cut box (scene.cpp:251):
@@ -488,8 +489,8 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
     const V3 o = W.o, d = W.d;
     const uint32_t cur = W.cur, ca = W.ca, cb = W.cb, cr = W.cr;
     const uint32_t li = cur + 1u;
-    const bool has_l = li < ca; // ca = end of this subtree
-    const bool has_r = cr < ca;
+    const bool has_r = cr < ca;           // ca = end of this subtree
+    const bool has_l = li < ca && cr != li; // right == cur + 1: the next slot is a right-only child (kd_children in ptk.hip)
     const uint32_t ri = has_r ? cr : cur;
     const float4* __restrict__ ql = reinterpret_cast<const float4*>(kd + (has_l ? li : cur));
     const float4* __restrict__ qr = reinterpret_cast<const float4*>(kd + ri);

@@ -32,6 +32,11 @@ def render_iteration(backend, total, image, width, height, spi, iteration, seed=
     """One reported iteration.  `total` / `image` are torch tensors (H,W,3) on the backend's
     device; on return rank 0's `image` holds the running mean, `total` the reduced sum."""
     p0, np_, s0, ns = iteration_share(width, height, spi, iteration, rank, world)
+    if getattr(total, "is_cuda", False) and hasattr(backend, "set_stream"):
+        # total.zero_() and the reduce run on torch's current stream (RCCL orders itself against it); the
+        # library's kernels must be enqueued on that same stream or they race with both
+        import torch
+        backend.set_stream(torch.cuda.current_stream(total.device).cuda_stream)
     if world > 1:
         total.zero_()  # pixels / samples outside this rank's share contribute 0 to the reduce
     if np_ > 0 and ns > 0:

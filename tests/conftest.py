@@ -91,3 +91,32 @@ def random_rays(n, seed, lo, hi):
     d = rng.normal(0, 1, (n, 3))
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     return o, d
+
+
+def planar_cluster(n_tris, seed, x, size=0.12):
+    """Triangles whose vertices all lie in the plane x = `x` (random in y, z, both windings).  Every split on
+    the x axis then has all 3n coordinates equal, and the reference's sequential fp32 mean (scene.cpp:240-249)
+    rounds just below or just above them: the node gets ONE child (scene.cpp:280-284), a right-only child when the
+    mean rounds down, a left-only child when it rounds up."""
+    tris = random_soup(n_tris, seed, extent=1.0, size=size)
+    tris[:, :, 0] = np.float32(x)
+    return tris
+
+
+def single_child_nodes(nodes, info):
+    """(left_only, right_only) interior-node counts of a ptk_kd_build tree: a lone child that keeps the parent's
+    min on the split axis is the left child (scene.cpp:31-56), otherwise the right one."""
+    left_only = right_only = 0
+    for i in range(info.num_nodes):
+        n = nodes[i]
+        if n.num_prims or i + 1 >= n.skip:
+            continue
+        c = nodes[i + 1]
+        if c.skip < n.skip:
+            continue  # two children
+        axis = n.depth % 3
+        if np.float32(c.bmin[axis]).view(np.uint32) != np.float32(n.bmin[axis]).view(np.uint32):
+            right_only += 1
+        else:
+            left_only += 1
+    return left_only, right_only

@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT, get_oracle, get_scene, random_soup
+from conftest import ROOT, get_oracle, get_scene, planar_cluster, random_soup, single_child_nodes
 from pathtracing_amd import _abi, glmath, kd_build, scene as S
 from pathtracing_amd import parallel
 
@@ -80,6 +80,23 @@ def test_kd_flattener_on_mario():
         assert i < nodes[i].skip <= info.num_nodes
         if nodes[i].num_prims:
             assert nodes[i].skip == i + 1
+
+
+@pytest.mark.parametrize("x,n,kind", [(0.1, 400, "right"), (0.7, 400, "left"), (-0.1, 401, "left"), (-0.7, 1000, "left"), (0.3, 1000, "right")])
+def test_kd_single_child_interior_nodes(x, n, kind):
+    """A planar cluster at a non-dyadic x: the fp32 mean rounds off the plane, so interior nodes on the x axis get one
+    child only (scene.cpp:280-284).  The builder equals the oracle's pointer tree and really holds such nodes."""
+    from oracle import oracle
+    tris = planar_cluster(n, 21, x)
+    sc = S.Scene()
+    node = S.SceneNode()
+    node.shape = S.Mesh(tris)
+    sc.nodes.append(node)
+    got = kd_build(tris)
+    kd_equal(got, oracle.OracleScene(sc).kd_export(0))
+    left_only, right_only = single_child_nodes(got[1], got[0])
+    assert (right_only if kind == "right" else left_only) > 0, (left_only, right_only)
+    assert got[0].num_nodes > 20
 
 
 def test_kd_degenerate_identical_triangles():

@@ -245,6 +245,25 @@ int ptk_render_samples_dev(ptk_ctx* ctx, uint64_t seed,
                            uint64_t sample_begin, uint32_t sample_count,
                            float* sum_rgb_dev, int accumulate);
 
+/* ptk_render_samples_dev for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight display loops (Sandbox re-renders on every camera move, rtsb.cpp:295-299,355),
+ * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same kernels
+ * and the same sums, but the ray queues, per-sample radiance and parked-ray records live in a static
+ * device array of the library (about 41 MiB per GPU, held until the process ends) instead of the
+ * buffers ptk_render_begin / ptk_render_samples_dev allocate; the call itself makes no hipMalloc /
+ * hipFree / event creation (ptk_ctx_enable_timing records nothing for it).
+ * Limit: pixel_count * sample_count <= PTK_NOALLOC_MAX_PATHS, else PTK_ERR_INVALID (split the pixel
+ * or sample range over several calls; with accumulate = 1 the sums of sample sub-ranges add up).
+ * ptk_scene_upload and ptk_render_begin (which do allocate) must have been called before, outside
+ * the no-allocation region; pass ptk_render_begin a small max_paths_per_launch if only this entry
+ * point is used.  All contexts on one GPU share the array: calls that overlap on one GPU race, so
+ * serialise them (one stream, or events between streams). */
+#define PTK_NOALLOC_MAX_PATHS (1u << 18)
+int ptk_render_samples_noalloc_dev(ptk_ctx* ctx, uint64_t seed,
+                                   uint64_t pixel_begin, uint64_t pixel_count,
+                                   uint64_t sample_begin, uint32_t sample_count,
+                                   float* sum_rgb_dev, int accumulate);
+
 /* abstract_pathtracer.cpp:66,88-90: image = mix(sum/spi, image, it/float(it+1)). */
 int ptk_resolve_iteration_dev(ptk_ctx* ctx, const float* sum_rgb_dev, float* image_rgb_dev,
                               uint64_t samples_per_iteration, uint64_t iteration);

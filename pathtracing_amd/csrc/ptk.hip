@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,18 @@ void ptk_kd_build_vectors(const ptk_triangle* triangles, uint64_t num_triangles,
                           std::vector<ptk_kd_node>& nodes, std::vector<uint32_t>& prims);
 
 using namespace ptk;
+
+// ---- static scratch of the entry point that allocates nothing (ptk_render_samples_noalloc_dev) ----
+// Ray queues, per-sample radiance, segment counters and the parked-ray records of one launch chain of at
+// most PTK_NOALLOC_MAX_PATHS paths, laid out by NoallocLayout below.  Every GPU the library runs on holds
+// its own copy until the process ends.  Host code never uses the array's name as an address: the per-device
+// address comes from hipGetSymbolAddress (noalloc_scratch_for) and is what kernels and memsets receive.
+constexpr uint64_t kNoallocPaths = PTK_NOALLOC_MAX_PATHS;
+constexpr uint64_t kNoallocSegments = kNoallocPaths / 256;
+constexpr uint64_t kNoallocWordsPerPath = 13 + 13 + 3 + 1 + 2 + 9; // two queues, sample_L, pend_slot, pend_mask, pend_best
+constexpr uint64_t kNoallocBytes =
+    kNoallocPaths * kNoallocWordsPerPath * 4 + (kNoallocSegments * (PTK_MAX_DEPTH + 1) + 2 * PTK_MAX_DEPTH) * 4 + 8 * 256;
+static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
 
 namespace {
 
@@ -842,6 +855,7 @@ struct ptk_ctx {
 
     // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
     bool timing = false;
+    bool timing_hold = false; // set while the no-alloc entry point runs: HIP events are allocations
     struct Stamp {
         int kind;
         hipEvent_t a, b;
@@ -1206,7 +1220,7 @@ struct LaunchTimer {
     bool on = false;
     LaunchTimer(ptk_ctx* ctx, int kind) : c(ctx)
     {
-        if (!c->timing || c->stamps.size() >= kMaxStamps) return;
+        if (!c->timing || c->timing_hold || c->stamps.size() >= kMaxStamps) return;
         if (hipEventCreate(&st.a) != hipSuccess) return;
         if (hipEventCreate(&st.b) != hipSuccess) {
             (void)hipEventDestroy(st.a);
@@ -1273,8 +1287,8 @@ uint32_t walk_chunk_for(uint32_t num_segments)
 
 constexpr uint64_t kDeviceKdMinTriangles = 32768; // PTK_OPT_DEVICE_KD = 2: meshes at least this large build on the GPU
 
-// The launch chain of ptk_render_samples_dev over the scratch buffers `R`
-// (the context's own allocations): chunks of at most R.cap paths, five bounces each.
+// The launch chain of ptk_render_samples_dev / ptk_render_samples_noalloc_dev over the scratch buffers `R`
+// (the context's own allocations or the static array): chunks of at most R.cap paths, five bounces each.
 struct RenderBufs {
     float* state;                 // queue 0: kStateFields arrays of `cap` floats
     float* state2;                // queue 1 (split mode)
@@ -1287,6 +1301,50 @@ struct RenderBufs {
     float* pend_best;             // 9 arrays of `cap` floats
     uint64_t cap;
 };
+
+// Device address of `scratch` on each GPU (every device holds its own copy at its own address), looked up
+// once per device by ptk_ctx_create with that device current.
+constexpr int kMaxDevices = 64;
+std::mutex g_noalloc_mutex;
+void* g_noalloc_ptr[kMaxDevices] = {};
+hipError_t g_noalloc_err[kMaxDevices] = {};
+bool g_noalloc_done[kMaxDevices] = {};
+
+void noalloc_scratch_init(int device) // the caller has made `device` current
+{
+    if (device < 0 || device >= kMaxDevices) return;
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (g_noalloc_done[device]) return;
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    g_noalloc_err[device] = e;
+    g_noalloc_ptr[device] = e == hipSuccess ? ptr : nullptr;
+    g_noalloc_done[device] = true;
+}
+
+// Carves the static array (base = its device address) into the buffers of one launch chain.
+RenderBufs noalloc_layout(void* base)
+{
+    unsigned char* p = static_cast<unsigned char*>(base);
+    auto take = [&](uint64_t bytes) {
+        unsigned char* r = p;
+        p += (bytes + 255u) & ~uint64_t(255);
+        return r;
+    };
+    RenderBufs R{};
+    R.cap = kNoallocPaths;
+    R.pend_mask = reinterpret_cast<unsigned long long*>(take(kNoallocPaths * 8));
+    R.state = reinterpret_cast<float*>(take(kNoallocPaths * kStateFields * 4));
+    R.state2 = reinterpret_cast<float*>(take(kNoallocPaths * kStateFields * 4));
+    R.sample_L = reinterpret_cast<float*>(take(kNoallocPaths * 3 * 4));
+    R.pend_slot = reinterpret_cast<uint32_t*>(take(kNoallocPaths * 4));
+    R.pend_best = reinterpret_cast<float*>(take(kNoallocPaths * 9 * 4));
+    R.seg_count = reinterpret_cast<uint32_t*>(take(kNoallocSegments * PTK_MAX_DEPTH * 4));
+    R.seg_pend = reinterpret_cast<uint32_t*>(take(kNoallocSegments * 4));
+    R.split_counters = reinterpret_cast<uint32_t*>(take(kSplitCounters * 4));
+    if ((uint64_t)(p - static_cast<unsigned char*>(base)) > kNoallocBytes) R.cap = 0; // cannot happen: see kNoallocBytes
+    return R;
+}
 
 int set_device(ptk_ctx* c)
 {
@@ -1434,6 +1492,7 @@ int ptk_ctx_create(int device, ptk_ctx** out)
         return PTK_ERR_HIP;
     }
     c->stream = c->own_stream;
+    noalloc_scratch_init(device); // `device` is current here
     *out = c;
     return PTK_OK;
 }
@@ -2048,6 +2107,44 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
     R.pend_best = c->d_pend_best;
     R.cap = cap;
     return render_samples_impl(c, R, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb, accumulate);
+}
+
+int ptk_render_samples_noalloc_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint64_t pixel_count, uint64_t sample_begin,
+                                   uint32_t sample_count, float* sum_rgb, int accumulate)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene || !c->has_view) return fail(c, PTK_ERR_STATE, "ptk_render_samples_noalloc: call ptk_render_begin first");
+    if (!sum_rgb) return fail(c, PTK_ERR_INVALID, "ptk_render_samples_noalloc: NULL sum buffer");
+    const uint64_t num_pixels = (uint64_t)c->V.width * c->V.height;
+    if (pixel_begin > num_pixels || pixel_count > num_pixels - pixel_begin)
+        return fail(c, PTK_ERR_INVALID, "ptk_render_samples_noalloc: pixel range outside the viewport");
+    if (pixel_count * (uint64_t)sample_count > kNoallocPaths) // pixel_count < 2^32, sample_count < 2^32: no overflow
+        return fail(c, PTK_ERR_INVALID, "ptk_render_samples_noalloc: pixel_count * sample_count = " +
+                                            std::to_string(pixel_count * (uint64_t)sample_count) + " exceeds PTK_NOALLOC_MAX_PATHS = " +
+                                            std::to_string(kNoallocPaths) + " (split the pixel or sample range over several calls)");
+    if (pixel_count == 0) return PTK_OK;
+    if (int r = set_device(c)) return r;
+    if (sample_count == 0) {
+        if (!accumulate) PTK_HIP(c, hipMemsetAsync(sum_rgb + pixel_begin * 3, 0, pixel_count * 3 * sizeof(float), c->stream));
+        return PTK_OK;
+    }
+    void* base = nullptr;
+    if (c->device >= 0 && c->device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+        if (g_noalloc_done[c->device] && g_noalloc_err[c->device] != hipSuccess)
+            return fail(c, PTK_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(g_noalloc_err[c->device]));
+        base = g_noalloc_ptr[c->device];
+    }
+    if (!base) return fail(c, PTK_ERR_STATE, "ptk_render_samples_noalloc: no static scratch on this device");
+    const RenderBufs R = noalloc_layout(base);
+    if (R.cap != kNoallocPaths) return fail(c, PTK_ERR_STATE, "ptk_render_samples_noalloc: scratch layout exceeds the static array");
+    // one chunk by construction (n_paths <= R.cap); every counter the chain reads is written by the chain
+    // itself first (seg_count / seg_pend by the bounce kernels, the split counters by the memset in the
+    // chain), so nothing of the previous call's contents is ever read
+    c->timing_hold = true;
+    const int rc = render_samples_impl(c, R, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb, accumulate);
+    c->timing_hold = false;
+    return rc;
 }
 
 int ptk_resolve_iteration_dev(ptk_ctx* c, const float* sum_rgb, float* image_rgb, uint64_t spi, uint64_t iteration)

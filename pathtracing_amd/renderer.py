@@ -106,6 +106,13 @@ class Context:
         self._check(self._lib.ptk_render_samples_dev(self._h, seed, pixel_begin, pixel_count, sample_begin, sample_count,
                                                      sum_ptr, 1 if accumulate else 0))
 
+    def render_samples_noalloc_dev(self, seed, sample_begin, sample_count, sum_ptr, accumulate=False, pixel_begin=0, pixel_count=None):
+        """ptk_render_samples_noalloc_dev: same as render_samples_dev on the library's static scratch (no allocation)."""
+        if pixel_count is None:
+            pixel_count = self.width * self.height - pixel_begin
+        self._check(self._lib.ptk_render_samples_noalloc_dev(self._h, seed, pixel_begin, pixel_count, sample_begin, sample_count,
+                                                             sum_ptr, 1 if accumulate else 0))
+
     def resolve_iteration_dev(self, sum_ptr, image_ptr, spi, iteration):
         self._check(self._lib.ptk_resolve_iteration_dev(self._h, sum_ptr, image_ptr, spi, iteration))
 

@@ -278,6 +278,33 @@ int ptk_render_image(ptk_ctx* ctx, uint64_t seed, uint64_t iterations,
 int ptk_tonemap_dev(ptk_ctx* ctx, const float* image_rgb_dev, uint32_t* rgba8_dev,
                     uint64_t num_pixels);
 
+/* ---- probes of single device functions (parity entries, like ptk_intersect_batch) ----------
+ * Each runs one function of the path on caller-supplied inputs so that it can be held against
+ * the reference function it restates directly, edge cases included.  All arrays are device
+ * pointers, SoA like ptk_intersect_batch_dev ([x0..xn-1 | y.. | z..]).
+ *
+ * image::sample (sampler.cpp:36-61) of texture `texture` of the uploaded scene in `mode`
+ * (PTK_MODE_*) at uv (2n floats) -> rgb (3n floats). */
+int ptk_probe_image_sample_dev(ptk_ctx* ctx, uint32_t texture, uint32_t mode, uint64_t n,
+                               const float* uv_dev, float* rgb_dev);
+/* scene.background->sample(direction) (pathtracer.cpp:67): color_sampler (sampler.h:58) or
+ * equirectangular_map::sample (sampler.cpp:116-124); directions 3n floats -> rgb 3n floats. */
+int ptk_probe_background_dev(ptk_ctx* ctx, uint64_t n, const float* directions_dev, float* rgb_dev);
+/* rng::hemisphere (rng.cpp:12-36) around normals (3n floats) with the two uniform draws of
+ * rng.cpp:27,29 supplied in u12 (2n floats: z, then the phi draw) -> directions (3n floats). */
+int ptk_probe_hemisphere_dev(ptk_ctx* ctx, uint64_t n, const float* normals_dev, const float* u12_dev,
+                             float* directions_dev);
+/* One level of pathtracer::trace_recursive (pathtracer.cpp:29-68) for n caller rays, with the
+ * hemisphere draws supplied in u12: scene::cast_ray, then for a hit the material lookups, the
+ * bounce direction and the next ray.  Outputs (any may be NULL): node = index of the hit node or
+ * -1; emission = material emission at the hit, or the background's colour for a miss (3n);
+ * weight = mix(albedo, 1, metallic) * cos_theta * 2, the factor of pathtracer.cpp:60 on the
+ * next ray's radiance (3n; 0 for a miss); next_origin / next_direction = reflected_ray of
+ * pathtracer.cpp:47-51 (3n each; the input ray for a miss). */
+int ptk_probe_shade_dev(ptk_ctx* ctx, uint64_t n, const float* origins_dev, const float* directions_dev,
+                        const float* u12_dev, int32_t* node_dev, float* emission_dev, float* weight_dev,
+                        float* next_origin_dev, float* next_direction_dev);
+
 /* Device ray / path counters since the last reset (synchronises). */
 int ptk_get_counters(ptk_ctx* ctx, ptk_counters* out);
 int ptk_reset_counters(ptk_ctx* ctx);

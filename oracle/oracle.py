@@ -51,6 +51,8 @@ def load():
         lib.orc_secondary_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_set_walk_model.argtypes = [C.c_int]
+        lib.orc_tonemap.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        lib.orc_shade_probe.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 8
         _lib = lib
     return _lib
 
@@ -161,6 +163,34 @@ class OracleScene:
         self._lib.orc_secondary_rays(self._h, w, h, float(np.float32(fov_y)), seed, n, pixel.ctypes.data,
                                      sample.ctypes.data, o.ctypes.data, d.ctypes.data, valid.ctypes.data)
         return np.ascontiguousarray(o.T), np.ascontiguousarray(d.T), valid.astype(bool)
+
+
+def _shade_probe(self, origins, directions, u12):
+    """One level of trace_recursive with supplied draws -> dict like Context.probe_shade."""
+    o = np.ascontiguousarray(np.asarray(origins, np.float32).reshape(-1, 3).T)
+    d = np.ascontiguousarray(np.asarray(directions, np.float32).reshape(-1, 3).T)
+    u = np.ascontiguousarray(np.asarray(u12, np.float32).reshape(-1, 2).T)
+    n = o.shape[1]
+    out = {"node": np.empty(n, np.int32)}
+    bufs = {k: np.empty((3, n), np.float32) for k in ("emission", "weight", "next_origin", "next_direction")}
+    self._lib.orc_shade_probe(self._h, n, o.ctypes.data, d.ctypes.data, u.ctypes.data, out["node"].ctypes.data,
+                              *[bufs[k].ctypes.data for k in ("emission", "weight", "next_origin", "next_direction")])
+    for k, v in bufs.items():
+        out[k] = np.ascontiguousarray(v.T)
+    return out
+
+
+OracleScene.shade_probe = _shade_probe
+
+
+def tonemap(image_rgb):
+    """CLI/main.cpp:91-103 -> (rgba uint32 per pixel, the float products c * 255 before truncation)."""
+    lib = load()
+    img = np.ascontiguousarray(image_rgb, np.float32).reshape(-1, 3)
+    rgba = np.empty(img.shape[0], np.uint32)
+    scaled = np.empty_like(img)
+    lib.orc_tonemap(img.ctypes.data, img.shape[0], rgba.ctypes.data, scaled.ctypes.data)
+    return rgba, scaled
 
 
 def resolve_iteration(sum_rgb, image_rgb, spi, iteration):

@@ -1055,6 +1055,62 @@ void orc_hemisphere(uint64_t n, const float* normal, const float* u12, float* ou
     }
 }
 
+/* One level of pathtracer::trace_recursive (pathtracer.cpp:29-68) with the two hemisphere draws supplied: cast, then
+ * for a hit the material lookups (:34-37), hemisphere / reflect / mix direction (:40-45), the next ray (:47-51) and
+ * the factor mix(albedo, 1, metallic) * cos_theta * 2 of :60; for a miss the background (:67).  SoA arrays of n. */
+void orc_shade_probe(const orc_scene* s, uint64_t n, const float* o, const float* d, const float* u12, int32_t* node_out,
+                     float* emission, float* weight, float* next_o, float* next_d)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        ray_t r;
+        r.o = V3(o[i], o[n + i], o[2 * n + i]);
+        r.d = V3(d[i], d[n + i], d[2 * n + i]);
+        int32_t node;
+        const hit_t res = scene_cast_ray(s, &r, &node, NULL, NULL);
+        v3 e, w = V3(0.0f, 0.0f, 0.0f), no = r.o, nd = r.d;
+        if (res.hit) {
+            const ptk_node_desc* ndp = &s->nodes[node];
+            const v3 albedo = sampler_sample(s, ndp->albedo, res.uv);
+            e = sampler_sample(s, ndp->emission, res.uv);
+            const float roughness = sampler_sample(s, ndp->roughness, res.uv).x;
+            const float metallic = sampler_sample(s, ndp->metallic, res.uv).x;
+            const v3 hemi_dir = hemisphere_dir(res.normal, u12[i], u12[n + i]);
+            const v3 reflect_dir = sub3(r.d, scale3(scale3(res.normal, dot3(res.normal, r.d)), 2.0f));
+            const v3 dir = normalize3(mix3(reflect_dir, hemi_dir, roughness));
+            no = add3(res.position, scale3(dir, PTK_EPSILON));
+            nd = dir;
+            const float dn = dot3(dir, res.normal);
+            const float cos_theta = (0.0f < dn) ? dn : 0.0f;
+            w = scale3(scale3(mix3(albedo, V3(1.0f, 1.0f, 1.0f), metallic), cos_theta), 2.0f);
+        } else {
+            e = background_sample(s, r.d);
+            node = -1;
+        }
+        node_out[i] = node;
+        emission[i] = e.x; emission[n + i] = e.y; emission[2 * n + i] = e.z;
+        weight[i] = w.x; weight[n + i] = w.y; weight[2 * n + i] = w.z;
+        next_o[i] = no.x; next_o[n + i] = no.y; next_o[2 * n + i] = no.z;
+        next_d[i] = nd.x; next_d[n + i] = nd.y; next_d[2 * n + i] = nd.z;
+    }
+}
+
+/* CLI/main.cpp:91-103: tone map 1 - exp(-c), gamma pow(c, 1/2.2), truncating uint32(c * 255) per channel, alpha 255.
+ * Also returns the pre-truncation products c * 255 (3 floats per pixel) so that a test can tell a last-place
+ * difference of a device expf / powf at an integer boundary from a real one. */
+void orc_tonemap(const float* rgb, uint64_t n, uint32_t* rgba, float* scaled)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t px = 255u << 24;
+        for (int c = 0; c < 3; ++c) {
+            float v = 1.0f - expf(-rgb[3 * i + c]);
+            v = powf(v, 1.0f / 2.2f);
+            if (scaled) scaled[3 * i + c] = v * 255;
+            px |= ((uint32_t)(v * 255)) << (8 * c);
+        }
+        rgba[i] = px;
+    }
+}
+
 void orc_primary_rays(const orc_scene* s, uint32_t w, uint32_t h, float fov_y, uint64_t n, const uint32_t* xy,
                       const float* u12, float* o, float* d)
 {

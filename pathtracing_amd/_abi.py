@@ -140,6 +140,10 @@ SYMBOLS = {
     "ptk_resolve_iteration_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "ptk_render_image": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "ptk_tonemap_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ptk_probe_image_sample_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "ptk_probe_background_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "ptk_probe_hemisphere_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptk_probe_shade_dev": (C.c_int, [C.c_void_p, C.c_uint64] + [C.c_void_p] * 8),
     "ptk_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "ptk_reset_counters": (C.c_int, [C.c_void_p]),
     "ptk_ctx_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -126,6 +126,36 @@ struct BounceArgs {
     uint32_t bounce;
 };
 
+// pathtracer::trace_recursive for one hit (pathtracer.cpp:34-60) with the two hemisphere draws supplied: samples the
+// node's material at the hit, returns its emission, the factor mix(albedo, 1, metallic) * cos_theta * 2 the
+// radiance of the next ray is weighted with, and that next ray (position + dir * epsilon, dir).
+__device__ __forceinline__ void shade_hit(const DScene& S, const Hit& h, V3 d, float u1, float u2, V3& emission, V3& weight,
+                                          V3& o_next, V3& d_next)
+{
+    V3 n;
+    float uvx, uvy, uu, vv;
+    int prim_id;
+    hit_attributes<false>(S, h, n, uvx, uvy, prim_id, uu, vv);
+    // pathtracer.cpp:34-37
+    const DSampler* __restrict__ ms = S.node_samplers + (size_t)h.node * 4;
+    const DSampler s_albedo = ms[0], s_emission = ms[1], s_roughness = ms[2], s_metallic = ms[3];
+    const V3 albedo = sampler_sample(S, s_albedo, uvx, uvy);
+    emission = sampler_sample(S, s_emission, uvx, uvy);
+    const float roughness = sampler_sample(S, s_roughness, uvx, uvy).x;
+    const float metallic = sampler_sample(S, s_metallic, uvx, uvy).x;
+    // pathtracer.cpp:40-54
+    const V3 hemi = hemisphere_dir(n, u1, u2);
+    const V3 refl = d - n * dot(n, d) * 2.0f;
+    const V3 dir = normalize(mix(refl, hemi, roughness));
+    const float dn = dot(dir, n);
+    const float cos_theta = (0.0f < dn) ? dn : 0.0f;
+    // pathtracer.cpp:60
+    const V3 m = mix(albedo, mk(1.0f, 1.0f, 1.0f), metallic);
+    weight = m * cos_theta * 2.0f;
+    o_next = h.pw + dir * PTK_EPSILON;
+    d_next = dir;
+}
+
 // pathtracer::trace_recursive for one cast (pathtracer.cpp:29-68) in throughput form: updates L, and
 // for a hit before the last bounce turns (o, d, T) into the next ray.  Returns whether the path goes
 // on; a path that ends (miss, depth 5, zero throughput) writes its radiance to sample_L[path].
@@ -796,6 +826,74 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float* __restrict__ im
         px |= ((uint32_t)(v * 255) & 0xFFu) << (8 * c);
     }
     rgba[i] = px;
+}
+
+// ---- probes: the device functions of the samplers, the hemisphere mapping and one shading step, run on caller
+// data so that tests can hold each of them against the oracle directly (ptk_probe_*_dev) --------------------------
+// image::sample (sampler.cpp:36-61) on texture `tex` of the uploaded scene; uv / rgb are SoA arrays of n
+__global__ __launch_bounds__(kBlock) void k_probe_image(const DScene S, uint32_t tex, uint32_t mode, uint64_t n,
+                                                        const float* __restrict__ uv, float* __restrict__ rgb)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const V3 c = image_sample(S.textures[tex], mode, uv[i], uv[n + i]);
+    rgb[i] = c.x; rgb[n + i] = c.y; rgb[2 * n + i] = c.z;
+}
+
+// scene.background->sample(direction): color_sampler or equirectangular_map::sample (sampler.cpp:116-124)
+__global__ __launch_bounds__(kBlock) void k_probe_background(const DScene S, uint64_t n, const float* __restrict__ dir,
+                                                             float* __restrict__ rgb)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const V3 c = background_sample(S, mk(dir[i], dir[n + i], dir[2 * n + i]));
+    rgb[i] = c.x; rgb[n + i] = c.y; rgb[2 * n + i] = c.z;
+}
+
+// rng::hemisphere (rng.cpp:12-36) with the two draws supplied
+__global__ __launch_bounds__(kBlock) void k_probe_hemisphere(uint64_t n, const float* __restrict__ normal, const float* __restrict__ u12,
+                                                             float* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const V3 h = hemisphere_dir(mk(normal[i], normal[n + i], normal[2 * n + i]), u12[i], u12[n + i]);
+    out[i] = h.x; out[n + i] = h.y; out[2 * n + i] = h.z;
+}
+
+// One step of pathtracer::trace_recursive (pathtracer.cpp:29-68) for caller rays and caller draws: cast, then
+// shade_hit (hit) or the background (miss).
+struct ShadeProbeIO {
+    uint64_t n;
+    const float* o;
+    const float* d;
+    const float* u12;
+    int32_t* node;
+    float* emission;
+    float* weight;
+    float* next_o;
+    float* next_d;
+};
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_probe_shade(const DScene S, const ShadeProbeIO P)
+{
+    __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];
+    const uint64_t n = P.n;
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool on = i < n;
+    const uint64_t j = on ? i : 0;
+    const V3 ro = mk(P.o[j], P.o[n + j], P.o[2 * n + j]);
+    const V3 rd = mk(P.d[j], P.d[n + j], P.d[2 * n + j]);
+    Hit h;
+    intersect_scene_mode<MODE>(S, ro, rd, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
+    if (!on) return;
+    V3 e, w = mk(0.0f, 0.0f, 0.0f), no = ro, nd = rd;
+    if (h.node < 0) e = background_sample(S, rd); // pathtracer.cpp:67
+    else shade_hit(S, h, rd, P.u12[i], P.u12[n + i], e, w, no, nd);
+    if (P.node) P.node[i] = h.node;
+    if (P.emission) { P.emission[i] = e.x; P.emission[n + i] = e.y; P.emission[2 * n + i] = e.z; }
+    if (P.weight) { P.weight[i] = w.x; P.weight[n + i] = w.y; P.weight[2 * n + i] = w.z; }
+    if (P.next_o) { P.next_o[i] = no.x; P.next_o[n + i] = no.y; P.next_o[2 * n + i] = no.z; }
+    if (P.next_d) { P.next_d[i] = nd.x; P.next_d[n + i] = nd.y; P.next_d[2 * n + i] = nd.z; }
 }
 
 std::string g_create_error;
@@ -2197,6 +2295,72 @@ int ptk_tonemap_dev(ptk_ctx* c, const float* image_rgb, uint32_t* rgba8, uint64_
     if (int r = set_device(c)) return r;
     hipLaunchKernelGGL(k_tonemap, dim3((uint32_t)((num_pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
                        image_rgb, rgba8, num_pixels);
+    PTK_HIP(c, hipGetLastError());
+    return PTK_OK;
+}
+
+int ptk_probe_image_sample_dev(ptk_ctx* c, uint32_t texture, uint32_t mode, uint64_t n, const float* uv, float* rgb)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PTK_ERR_STATE, "ptk_probe_image_sample: no scene uploaded");
+    if (texture >= c->num_textures || mode > PTK_MODE_NEAREST) return fail(c, PTK_ERR_INVALID, "ptk_probe_image_sample: texture / mode out of range");
+    if (n == 0) return PTK_OK;
+    if (!uv || !rgb) return fail(c, PTK_ERR_INVALID, "ptk_probe_image_sample: NULL array");
+    if (n > 0x7FFFFFFFull * kBlock) return fail(c, PTK_ERR_INVALID, "ptk_probe_image_sample: too many probes");
+    if (int r = set_device(c)) return r;
+    k_probe_image<<<dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream>>>(c->S, texture, mode, n, uv, rgb);
+    PTK_HIP(c, hipGetLastError());
+    return PTK_OK;
+}
+
+int ptk_probe_background_dev(ptk_ctx* c, uint64_t n, const float* directions, float* rgb)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PTK_ERR_STATE, "ptk_probe_background: no scene uploaded");
+    if (n == 0) return PTK_OK;
+    if (!directions || !rgb) return fail(c, PTK_ERR_INVALID, "ptk_probe_background: NULL array");
+    if (n > 0x7FFFFFFFull * kBlock) return fail(c, PTK_ERR_INVALID, "ptk_probe_background: too many probes");
+    if (int r = set_device(c)) return r;
+    k_probe_background<<<dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream>>>(c->S, n, directions, rgb);
+    PTK_HIP(c, hipGetLastError());
+    return PTK_OK;
+}
+
+int ptk_probe_hemisphere_dev(ptk_ctx* c, uint64_t n, const float* normals, const float* u12, float* directions)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (n == 0) return PTK_OK;
+    if (!normals || !u12 || !directions) return fail(c, PTK_ERR_INVALID, "ptk_probe_hemisphere: NULL array");
+    if (n > 0x7FFFFFFFull * kBlock) return fail(c, PTK_ERR_INVALID, "ptk_probe_hemisphere: too many probes");
+    if (int r = set_device(c)) return r;
+    k_probe_hemisphere<<<dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream>>>(n, normals, u12, directions);
+    PTK_HIP(c, hipGetLastError());
+    return PTK_OK;
+}
+
+int ptk_probe_shade_dev(ptk_ctx* c, uint64_t n, const float* origins, const float* directions, const float* u12, int32_t* node,
+                        float* emission, float* weight, float* next_origin, float* next_direction)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene) return fail(c, PTK_ERR_STATE, "ptk_probe_shade: no scene uploaded");
+    if (n == 0) return PTK_OK;
+    if (!origins || !directions || !u12) return fail(c, PTK_ERR_INVALID, "ptk_probe_shade: NULL input array");
+    if (n > 0x7FFFFFFFull * kBlock) return fail(c, PTK_ERR_INVALID, "ptk_probe_shade: too many probes");
+    if (int r = set_device(c)) return r;
+    const ShadeProbeIO P{ n, origins, directions, u12, node, emission, weight, next_origin, next_direction };
+    const dim3 g((uint32_t)((n + kBlock - 1) / kBlock)), b(kBlock);
+#define PTK_PROBE(M) k_probe_shade<M><<<g, b, 0, c->stream>>>(c->S, P)
+    switch (kernel_mode(c, false)) {
+    case 0: PTK_PROBE(0); break;
+    case 1: PTK_PROBE(1); break;
+    case 2: PTK_PROBE(2); break;
+    case 3: PTK_PROBE(3); break;
+    case 5: PTK_PROBE(5); break;
+    case 7: PTK_PROBE(7); break;
+    case 8: PTK_PROBE(8); break;
+    default: PTK_PROBE(10); break;
+    }
+#undef PTK_PROBE
     PTK_HIP(c, hipGetLastError());
     return PTK_OK;
 }

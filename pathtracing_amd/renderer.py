@@ -124,6 +124,74 @@ class Context:
     def tonemap_dev(self, image_ptr, rgba_ptr, num_pixels):
         self._check(self._lib.ptk_tonemap_dev(self._h, image_ptr, rgba_ptr, num_pixels))
 
+    # ---- probes of single device functions (ptk_probe_*_dev); host arrays in, host arrays out ----
+    def _to_dev(self, arr):
+        a = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self._check(self._lib.ptk_dev_alloc(self._h, max(1, a.nbytes), C.byref(p)))
+        if a.nbytes:
+            self._check(self._lib.ptk_dev_upload(self._h, p, a.ctypes.data, a.nbytes))
+        return p
+
+    def _from_dev(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        self._check(self._lib.ptk_dev_download(self._h, out.ctypes.data, p, out.nbytes))
+        return out
+
+    def _free_dev(self, *ptrs):
+        for p in ptrs:
+            self._lib.ptk_dev_free(self._h, p)
+
+    def probe_image_sample(self, texture, mode, uv):
+        """image::sample of scene texture `texture` at uv (n,2) -> (n,3)."""
+        uv = np.asarray(uv, np.float32).reshape(-1, 2)
+        n = uv.shape[0]
+        d_uv, d_out = self._to_dev(uv.T), self._to_dev(np.zeros((3, n), np.float32))
+        try:
+            self._check(self._lib.ptk_probe_image_sample_dev(self._h, texture, mode, n, d_uv, d_out))
+            return np.ascontiguousarray(self._from_dev(d_out, (3, n), np.float32).T)
+        finally:
+            self._free_dev(d_uv, d_out)
+
+    def probe_background(self, directions):
+        d = np.asarray(directions, np.float32).reshape(-1, 3)
+        n = d.shape[0]
+        d_d, d_out = self._to_dev(d.T), self._to_dev(np.zeros((3, n), np.float32))
+        try:
+            self._check(self._lib.ptk_probe_background_dev(self._h, n, d_d, d_out))
+            return np.ascontiguousarray(self._from_dev(d_out, (3, n), np.float32).T)
+        finally:
+            self._free_dev(d_d, d_out)
+
+    def probe_hemisphere(self, normals, u12):
+        nr = np.asarray(normals, np.float32).reshape(-1, 3)
+        u = np.asarray(u12, np.float32).reshape(-1, 2)
+        n = nr.shape[0]
+        d_n, d_u, d_out = self._to_dev(nr.T), self._to_dev(u.T), self._to_dev(np.zeros((3, n), np.float32))
+        try:
+            self._check(self._lib.ptk_probe_hemisphere_dev(self._h, n, d_n, d_u, d_out))
+            return np.ascontiguousarray(self._from_dev(d_out, (3, n), np.float32).T)
+        finally:
+            self._free_dev(d_n, d_u, d_out)
+
+    def probe_shade(self, origins, directions, u12):
+        """One level of trace_recursive -> dict(node, emission, weight, next_origin, next_direction)."""
+        o = np.asarray(origins, np.float32).reshape(-1, 3)
+        d = np.asarray(directions, np.float32).reshape(-1, 3)
+        u = np.asarray(u12, np.float32).reshape(-1, 2)
+        n = o.shape[0]
+        z3 = np.zeros((3, n), np.float32)
+        ptrs = [self._to_dev(o.T), self._to_dev(d.T), self._to_dev(u.T), self._to_dev(np.zeros(n, np.int32)),
+                self._to_dev(z3), self._to_dev(z3), self._to_dev(z3), self._to_dev(z3)]
+        try:
+            self._check(self._lib.ptk_probe_shade_dev(self._h, n, *ptrs))
+            out = {"node": self._from_dev(ptrs[3], (n,), np.int32)}
+            for k, p in zip(("emission", "weight", "next_origin", "next_direction"), ptrs[4:]):
+                out[k] = np.ascontiguousarray(self._from_dev(p, (3, n), np.float32).T)
+            return out
+        finally:
+            self._free_dev(*ptrs)
+
     def counters(self):
         c = _abi.Counters()
         self._check(self._lib.ptk_get_counters(self._h, C.byref(c)))

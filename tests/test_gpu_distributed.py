@@ -12,7 +12,10 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("scene,w,h,spi", [("room", 48, 32, 16), ("materials", 40, 40, 1), ("mario", 32, 32, 6)])
+# the last two: config 4's frame (Room 1024x1024) split over two ranks by sample range and, with fewer samples than
+# ranks, by pixel range (image tiles)
+@pytest.mark.parametrize("scene,w,h,spi", [("room", 48, 32, 16), ("materials", 40, 40, 1), ("mario", 32, 32, 6),
+                                          ("room", 1024, 1024, 4), ("room", 1024, 1024, 1)])
 def test_two_ranks_reproduce_one_rank(scene, w, h, spi):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

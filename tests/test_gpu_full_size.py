@@ -7,11 +7,18 @@ reference's tree copies triangles into leaves: 23.8 M x 160 B): size-independent
      the scene uploaded with the host-built tree;
   3. each hit is self-consistent: position = origin + t * direction, and position = M (v0 + u e0 + v e1) with the
      reported triangle's vertices (the primitive id names the triangle that was hit);
-  4. no hit is reported from behind (one-sided triangles, scene.cpp:149-158)."""
+  4. no hit is reported from behind (one-sided triangles, scene.cpp:149-158);
+  5. the RENDER leg at config 5's frame (2048x2048, 4096^2 albedo texture, bg0.hdr equirect background): counters,
+     repeatability, finite non-negative radiance, and bitwise the same image from the walker kernel, the in-kernel
+     pruned walk and the reference-order walk; at a size the oracle reaches (50 000 triangles, same texture kind and
+     background) the same-sample image equals the oracle's.
+Config 4 (Room 1024x1024 on 8 GPUs): the frame is rendered here on one GPU (counters, closedness of the room, 4x4
+box filter == the 256x256 render of the same pixel footprints); its 2-rank partition runs in
+tests/test_gpu_distributed.py."""
 import numpy as np
 import pytest
 
-from conftest import random_rays
+from conftest import ASSETS, get_scene, random_rays
 from test_gpu_kd_build import assert_same_tree
 
 pytestmark = pytest.mark.gpu
@@ -25,10 +32,27 @@ MODES = {  # PTK_OPT_TRAVERSAL, PTK_OPT_KD_PRUNE, PTK_OPT_NODE_CULL, PTK_OPT_BAL
 }
 
 
+_c5 = {}
+
+
+def config5_scene():
+    """BASELINE config 5 as bench.py --workload synthetic builds it: 5 M triangles, 4096^2 texture, bg0.hdr."""
+    import os
+    from pathtracing_amd import scene as S, workloads
+    if "scene" not in _c5:
+        bg = S.load_image(os.path.join(ASSETS, "res", "textures", "bg0.hdr"))
+        _c5["scene"] = workloads.synthetic_scene(5_000_000, 4096, bg)
+    return _c5["scene"]
+
+
+def rel_mse(i, r):
+    return float(np.mean((i - r) ** 2 / (r ** 2 + 1e-2)))
+
+
 def test_config5_mesh_at_full_size(_gpu_ctx_session):
-    from pathtracing_amd import _abi, kd_build, workloads
+    from pathtracing_amd import _abi, kd_build
     ctx = _gpu_ctx_session
-    sc = workloads.synthetic_scene(5_000_000, 256)
+    sc = config5_scene()
     node = sc.nodes[0]
     tris = node.shape.triangles
     assert tris.shape[0] == 5_000_000
@@ -82,3 +106,109 @@ def test_config5_mesh_at_full_size(_gpu_ctx_session):
     n_local = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 1])
     n_world = n_local @ np.linalg.inv(m[:3, :3])  # (M^-T n)^T = n^T M^-1
     assert (np.einsum("ij,ij->i", n_world, d64) < 0).all()
+
+
+def test_config5_render_at_full_size(_gpu_ctx_session):
+    """The render leg of config 5 at its frame size: 2048x2048, 4096^2 texture, equirect bg0.hdr, 5 M triangles."""
+    import torch
+    from pathtracing_amd import _abi
+    ctx = _gpu_ctx_session
+    sc = config5_scene()
+    tex = sc.nodes[0].material.albedo
+    assert (tex.width, tex.height) == (4096, 4096) and sc.background.image.width == 1024
+    dev = torch.device("cuda", 0)
+    w = h = 2048
+    spp = 4
+    imgs = {}
+    try:
+        for name, (prune, split) in {"walker": (1, 2), "in-kernel pruned walk": (1, 0), "reference-order walk": (0, 0)}.items():
+            ctx.set_option(_abi.PTK_OPT_KD_PRUNE, prune)
+            ctx.set_option(_abi.PTK_OPT_SPLIT, split)
+            ctx.upload(sc)
+            ctx.render_begin(w, h, np.pi / 4)
+            ctx.reset_counters()
+            a = torch.zeros(h, w, 3, device=dev)
+            ctx.render_samples_dev(0, 0, spp, a.data_ptr())
+            ctx.synchronize()
+            paths, rays = ctx.counters()
+            assert paths == w * h * spp
+            assert paths <= rays <= 5 * paths
+            imgs[name] = (a, rays)
+        b = torch.zeros(h, w, 3, device=dev)
+        ctx.render_samples_dev(0, 0, spp, b.data_ptr())   # last configuration again: repeatable
+        ctx.synchronize()
+        assert torch.equal(b, imgs["reference-order walk"][0])
+    finally:
+        ctx.set_option(_abi.PTK_OPT_KD_PRUNE, 1)
+        ctx.set_option(_abi.PTK_OPT_SPLIT, 2)
+    ref, ref_rays = imgs["reference-order walk"]
+    for name, (a, rays) in imgs.items():
+        assert rays == ref_rays, (name, rays, ref_rays)
+        assert torch.equal(a, ref), (name, int((a != ref).sum()))
+    img = (ref / spp).cpu().numpy()
+    assert np.isfinite(img).all() and (img >= 0).all()
+    # the sphere fills the middle of the frame (textured, lit by the sky), the corners see the sky: to_ldr is not
+    # applied to this background, so they carry bg0.hdr's radiance unchanged
+    centre, corner = img[900:1150, 900:1150], img[:64, :64]
+    assert 0.02 < centre.mean() < 5.0
+    bgmax = float(sc.background.image.pixels.max())
+    assert corner.max() <= bgmax * (1 + 1e-6)
+    assert 1.2 < ref_rays / (w * h * spp) < 3.0   # open scene: most paths leave after one or two bounces
+
+
+def test_config5_scene_at_oracle_size_same_samples(gpu_ctx):
+    """The config-5 scene kind at 50 000 triangles (deep KD-tree, 1024^2 image albedo sampled through interpolated uv,
+    equirect background): same-sample image against the oracle, every traversal mapping."""
+    import os
+    from oracle import oracle
+    from pathtracing_amd import scene as S, workloads
+    if "small" not in _c5:
+        bg = S.load_image(os.path.join(ASSETS, "res", "textures", "bg0.hdr"))
+        sc = workloads.synthetic_scene(50_000, 1024, bg)
+        _c5["small"] = (sc, oracle.OracleScene(sc))
+    sc, ora = _c5["small"]
+    gpu_ctx.upload(sc)
+    w, h, spp = 80, 64, 8
+    gpu_ctx.render_begin(w, h, np.pi / 4)
+    img = gpu_ctx.render_image(seed=17, iterations=1, spi=spp)
+    ref, _ = ora.render_image(w, h, np.pi / 4, 17, 1, spp, threads=8)
+    assert rel_mse(img, ref) < 1e-5, rel_mse(img, ref)
+    close = np.isclose(img, ref, rtol=2e-3, atol=2e-4).all(axis=2)
+    assert close.mean() > 0.98, close.mean()
+    assert ref[h // 2, w // 2].sum() > 0 and ref[0, 0].sum() > 0
+
+
+def test_config4_room_1024_frame(_gpu_ctx_session):
+    """Config 4's frame on one GPU: Room at 1024x1024, one CLI iteration (256 spp = 268 M paths)."""
+    import torch
+    ctx = _gpu_ctx_session
+    dev = torch.device("cuda", 0)
+    ctx.upload(get_scene("room"))
+    w = h = 1024
+    ctx.render_begin(w, h, np.pi / 4)
+    ctx.reset_counters()
+    big = torch.zeros(h, w, 3, device=dev)
+    ctx.render_samples_dev(5, 0, 256, big.data_ptr())
+    ctx.synchronize()
+    paths, rays = ctx.counters()
+    assert paths == w * h * 256
+    # the room is closed: every path casts all five rays, except paths whose throughput hits exactly 0 (dropped)
+    # and the rare ray that slips through a seam between two walls
+    assert 4.98 * paths <= rays <= 5 * paths, rays / paths
+    for k in range(1, 4):   # three more iterations' samples for the statistical comparison below
+        ctx.render_samples_dev(5, k * 256, 256, big.data_ptr(), accumulate=True)
+    ctx.synchronize()
+    img = (big / 1024).cpu().numpy()
+    assert np.isfinite(img).all() and (img >= 0).all()
+    # a 256x256 pixel covers the footprints of a 4x4 block of 1024x1024 pixels (jitter is uniform over the pixel,
+    # abstract_pathtracer.cpp:76-80): the box-filtered big frame estimates the same image as a 256x256 render with
+    # 16 x the samples.  Different samples, so the bar is statistical: 16384 spp per 256^2 pixel on both sides.
+    ctx.render_begin(256, 256, np.pi / 4)
+    small = ctx.render_image(seed=6, iterations=64, spi=256)
+    box = img.reshape(256, 4, 256, 4, 3).mean(axis=(1, 3))
+    b32 = lambda a: a.reshape(32, 8, 32, 8, 3).mean(axis=(1, 3))
+    ratio = b32(box).mean(axis=2) / b32(small).mean(axis=2)
+    assert abs(np.median(ratio) - 1.0) < 0.005, np.median(ratio)
+    # no next-event estimation: block ratios scatter by ~1 % at these sample counts with a heavy tail (98th percentile
+    # 8 %: rim of the lamp, the ball's highlight, dark corners), hence the 90th percentile
+    assert np.percentile(np.abs(ratio - 1.0), 90) < 0.05, np.percentile(np.abs(ratio - 1.0), 90)

@@ -1,0 +1,180 @@
+"""GPU parity of single device functions against the oracle (ptk_probe_*_dev, include/ptk.h): image::sample in both
+modes with the edge cases of sampler.cpp:36-61, equirectangular_map::sample, rng::hemisphere, one level of
+pathtracer::trace_recursive with supplied draws, and the CLI tone map.  Tolerances are stated per test: texel
+fetches and index arithmetic are exact; anything through device atan2f / asinf / sin / cos differs from the host
+libm in the last places."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, get_oracle, get_scene, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def texture_scene(pixels_list, modes):
+    """A scene whose only purpose is to carry textures: one sphere per texture, albedo = that image."""
+    from pathtracing_amd import scene as S
+    sc = S.Scene()
+    for px, mode in zip(pixels_list, modes):
+        node = S.SceneNode()
+        node.translate([3.0 * len(sc.nodes), 0.0, 0.0])
+        node.shape = S.Sphere()
+        node.material.albedo = S.Image(px, mode)
+        sc.nodes.append(node)
+    return sc
+
+
+def edge_uvs(w, h, rng):
+    """uv values around every place image::sample's arithmetic can turn: texel boundaries and centres (nearest mode
+    rounds half away from zero), fract(u) * W rounding up to exactly W, negative coordinates, the sphere's u range
+    [-0.5, 1.5] (scene.cpp:434-437), exact integers, signed zero."""
+    us = [0.0, -0.0, 1.0, -1.0, 2.0, 0.5, -0.5, 1.5, 0.25, 0.75, 1e-8, -1e-8, 1.0 - 2.0 ** -24, 1.0 - 2.0 ** -23,
+          -(2.0 ** -25), 3.0 - 2.0 ** -22, 7.999999, -7.999999, 123.456, -123.456]
+    for n in (w, h):
+        for k in range(0, n + 1, max(1, n // 7)):
+            for e in (0.0, 0.5, 1.0):
+                t = (k + e) / n
+                us += [t, np.nextafter(np.float32(t), np.float32(2)), np.nextafter(np.float32(t), np.float32(-2)), t - 1.0, t + 1.0]
+    us = np.array(us, np.float32)
+    grid = np.stack(np.meshgrid(us, us[::3]), axis=-1).reshape(-1, 2)
+    rand = rng.uniform(-2.5, 2.5, (20000, 2)).astype(np.float32)
+    return np.concatenate([grid, rand]).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def probe_ctx(_gpu_ctx_session):
+    return _gpu_ctx_session
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["linear", "nearest"])
+def test_image_sample_edge_cases(probe_ctx, mode):
+    """image::sample (sampler.cpp:36-61).  Bit-exact in nearest mode (a texel copy) and in linear mode (three mixes
+    of unfused fp32 products) for every finite uv, on: the reference's 2x2 checker-board.jpg, a 5x3 ramp, a 4095x3
+    strip (4095 is tuscany.jpg's width: fract(u) * W rounds to W there) and a 64x64 noise tile.  Nearest mode has
+    never run on the device through a scene (no reference scene uses it); this is its test."""
+    from oracle import oracle
+    from pathtracing_amd import scene as S
+    rng = np.random.default_rng(3)
+    checker = S.load_image(os.path.join(ASSETS, "res", "textures", "checker-board.jpg")).pixels
+    assert checker.shape == (2, 2, 3)
+    ramp = (np.arange(5 * 3 * 3, dtype=np.float32).reshape(3, 5, 3) + 1.0) / 7.0
+    strip = rng.uniform(0, 1, (3, 4095, 3)).astype(np.float32)
+    noise = rng.uniform(0, 4, (64, 64, 3)).astype(np.float32)
+    textures = [checker, ramp, strip, noise]
+    probe_ctx.upload(texture_scene(textures, ["linear"] * 4))
+    for t, px in enumerate(textures):
+        uv = edge_uvs(px.shape[1], px.shape[0], rng)
+        got = probe_ctx.probe_image_sample(t, mode, uv)
+        ref = oracle.sample_image(px, mode, uv)
+        assert np.array_equal(got, ref), (t, np.argwhere(got != ref)[:5], uv[np.argwhere((got != ref).any(axis=1))[:5, 0]])
+    # non-finite uv: the reference's own result is NaN arithmetic on an unspecified texel; require the same class
+    bad = np.array([[np.nan, 0.3], [0.3, np.inf], [-np.inf, np.nan]], np.float32)
+    got = probe_ctx.probe_image_sample(3, 0, bad)
+    assert np.isnan(got).all(axis=1).all()
+
+
+def test_equirect_background(probe_ctx):
+    """equirectangular_map::sample (sampler.cpp:116-124) on materials.json's bg0.hdr (to_ldr applied): random
+    directions, the poles, the +-z seam (u = 0 / 1), unnormalised and axis-aligned directions.  uv goes through
+    device atan2f / asinf, which differ from the host libm by a few ulp, i.e. by ~1e-6 of a texel... times the
+    local gradient of the map: 2e-3 absolute on values in [0, 1] after the 1 - exp(-x) map, and 99.9 % within 2e-5."""
+    from oracle import oracle
+    sc = get_scene("materials")
+    probe_ctx.upload(sc)
+    rng = np.random.default_rng(4)
+    d = rng.normal(0, 1, (200_000, 3)).astype(np.float32)
+    d[:1000] *= rng.uniform(0.01, 50.0, (1000, 1)).astype(np.float32)  # not normalised: the map normalises
+    special = np.array([[0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, 0, 0], [1e-7, 0, -1], [-1e-7, 0, -1],
+                        [1e-7, 0, 1], [-1e-7, 0, 1], [0, 0.9999999, 1e-4], [0.3, -0.9999999, 0.0]], np.float32)
+    d = np.concatenate([special, d])
+    got = probe_ctx.probe_background(d)
+    ref = oracle.sample_equirect(sc.background.image.pixels, 0, d)
+    err = np.abs(got - ref)
+    assert err.max() <= 2e-3, err.max()
+    assert (err.max(axis=1) <= 2e-5).mean() > 0.999, (err.max(axis=1) <= 2e-5).mean()
+    # a colour background is a constant (sampler.h:58)
+    probe_ctx.upload(get_scene("furnace"))
+    assert np.array_equal(probe_ctx.probe_background(d[:100]), np.ones((100, 3), np.float32))
+
+
+def test_hemisphere_mapping(probe_ctx):
+    """rng::hemisphere (rng.cpp:12-36): both tangent branches (|n.x| > |n.y| and not, including the tie), the draws'
+    corners (z = 0, z -> 1, phi = 0 and -> 2 pi).  The device evaluates sin / cos of 2 pi u with its own reduced-range
+    polynomials: 3e-7 absolute on unit vectors."""
+    from oracle import oracle
+    probe_ctx.upload(get_scene("furnace"))
+    rng = np.random.default_rng(5)
+    n = rng.normal(0, 1, (100_000, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    special = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [0.70710677, 0.70710677, 0],
+                        [-0.70710677, 0.70710677, 0], [0.57735026, 0.57735026, 0.57735026]], np.float32)
+    n = np.concatenate([special, n]).astype(np.float32)
+    u = rng.uniform(0, 1, (n.shape[0], 2)).astype(np.float32)
+    corners = np.array([[0, 0], [0, 0.25], [0, 0.5], [0, 0.75], [1 - 2.0 ** -24, 1 - 2.0 ** -24], [0.5, 1 - 2.0 ** -24], [1 - 2.0 ** -24, 0]],
+                       np.float32)
+    u[: len(corners)] = corners
+    got = probe_ctx.probe_hemisphere(n, u)
+    ref = oracle.hemisphere(n, u)
+    assert np.abs(got - ref).max() <= 3e-7, np.abs(got - ref).max()
+    # the mapping's own properties: unit length, z = u1 along the normal
+    assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() < 1e-5
+    assert np.abs((got * n).sum(axis=1) - u[:, 0]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name,lo,hi", [("room", -10, 10), ("materials", -8, 8), ("mario", -10, 10)])
+def test_shade_step(gpu_ctx, name, lo, hi):
+    """One level of pathtracer::trace_recursive (pathtracer.cpp:29-68) on random rays with supplied draws, under every
+    traversal mapping: hit node exact; emission exact for colour samplers; weight, next ray within 2e-5 (the bounce
+    direction goes through the device's sin / cos); Mario's 2048^2 texture lookups within 1e-5 for all but the rays
+    whose uv lands within rounding of a texel boundary."""
+    ora = get_oracle(name)
+    gpu_ctx.upload(get_scene(name))
+    n = 100_000 if name != "mario" else 40_000
+    o, d = random_rays(n, 321, lo, hi)
+    u = np.random.default_rng(6).uniform(0, 1, (n, 2)).astype(np.float32)
+    got = gpu_ctx.probe_shade(o, d, u)
+    ref = ora.shade_probe(o, d, u)
+    assert np.array_equal(got["node"], ref["node"])
+    hit = ref["node"] >= 0
+    assert hit.sum() > n // 10
+    assert np.array_equal(got["next_origin"][~hit], o[~hit]) and np.array_equal(got["weight"][~hit], np.zeros_like(o[~hit]))
+    if name == "materials":   # misses read the equirect map
+        assert np.abs(got["emission"][~hit] - ref["emission"][~hit]).max() <= 2e-3
+    else:
+        assert np.array_equal(got["emission"], ref["emission"])
+    tol = 2e-5
+    for k in ("next_origin", "next_direction"):
+        assert np.abs(got[k][hit] - ref[k][hit]).max() <= tol * max(1.0, abs(hi)), (k, np.abs(got[k][hit] - ref[k][hit]).max())
+    werr = np.abs(got["weight"][hit] - ref["weight"][hit]).max(axis=1)
+    if name == "mario":
+        assert (werr <= 1e-5).mean() > 0.999 and werr.max() < 0.5
+    else:
+        assert werr.max() <= tol, werr.max()
+
+
+def test_tonemap_exact(probe_ctx):
+    """ptk_tonemap_dev against CLI/main.cpp:91-103 restated with the host libm (oracle.tonemap): 1 - exp(-c),
+    pow(., 1/2.2), truncating uint32(c * 255).  Exact for every pixel whose product c * 255 is not within 1e-3 of an
+    integer (there a last-place difference of the device's expf / powf may truncate to the neighbouring level); those
+    may differ by one level at most."""
+    import torch
+    from oracle import oracle
+    rng = np.random.default_rng(8)
+    img = np.concatenate([rng.exponential(0.7, (200_000, 3)), rng.uniform(0, 0.02, (20_000, 3)), rng.uniform(5, 40, (5_000, 3)),
+                          np.array([[0, 0, 0], [1, 1, 1], [100, 1e-9, 0.5]])]).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(img).to(dev)
+    d_rgba = torch.empty(img.shape[0], dtype=torch.int32, device=dev)
+    probe_ctx.tonemap_dev(d_img.data_ptr(), d_rgba.data_ptr(), img.shape[0])
+    probe_ctx.synchronize()
+    got = d_rgba.cpu().numpy().view(np.uint8).reshape(-1, 4).astype(np.int32)
+    ref_rgba, scaled = oracle.tonemap(img)
+    ref = ref_rgba.view(np.uint8).reshape(-1, 4).astype(np.int32)
+    assert (got[:, 3] == 255).all() and (ref[:, 3] == 255).all()
+    near = np.abs(scaled - np.round(scaled)) < 1e-3
+    diff = np.abs(got[:, :3] - ref[:, :3])
+    assert (diff[~near] == 0).all(), np.argwhere((diff != 0) & ~near)[:5]
+    assert diff.max() <= 1
+    assert (diff != 0).mean() < 1e-4

@@ -377,6 +377,42 @@ int ptk_dev_upload(ptk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t b
 /* Flattened KD-tree the context holds for mesh `mesh` (tests, diagnostics). */
 int ptk_scene_kd_info(ptk_ctx* ctx, uint32_t mesh, ptk_kd_info* info);
 
+/* ---- several devices behind one host driver --------------------------
+ * The reference parallelises one run over host threads (abstract_pathtracer.cpp:97-103: num_threads
+ * workers share the scan lines of an iteration); a group does the same over GPUs.  Every member is a
+ * context on device_ids[m] (an id may repeat: two members on one GPU) holding the whole scene.  An
+ * iteration's samples are split over the members by sample range (by pixel range when there are fewer
+ * samples than members); sample indices are global, so the set of samples does not depend on the group
+ * size.  Each member accumulates a float SUM image; members on the same device are added on that device,
+ * the per-device sums are combined with one ncclReduce(sum) to member 0 over RCCL / xGMI (RCCL is loaded
+ * on first need; a group on one device never touches it), and member 0 applies
+ * image = mix(sum / spi, image, it / float(it + 1)) (abstract_pathtracer.cpp:88-90).
+ * An N-member image differs from the 1-member image only in the order of the per-pixel fp32 sum.
+ * Calls on a group are serialised by the caller, like calls on a context. */
+typedef struct ptk_group ptk_group;
+int ptk_group_create(const int* device_ids, int n, ptk_group** out);
+void ptk_group_destroy(ptk_group* group);
+/* Last error text of `group` (or of the last failed ptk_group_create if NULL). */
+const char* ptk_group_last_error(const ptk_group* group);
+int ptk_group_size(const ptk_group* group);
+/* Member context (options, per-member calls); NULL if out of range.  Owned by the group. */
+ptk_ctx* ptk_group_ctx(ptk_group* group, int member);
+/* ptk_scene_upload / ptk_scene_set_camera / ptk_render_begin on every member; render_begin also
+ * (re)allocates the per-member sum images and clears member 0's running-mean image. */
+int ptk_group_scene_upload(ptk_group* group, const ptk_scene_desc* scene);
+int ptk_group_scene_set_camera(ptk_group* group, const ptk_camera_desc* camera);
+int ptk_group_render_begin(ptk_group* group, uint32_t width, uint32_t height, float fov_y,
+                           uint64_t max_paths_per_launch);
+/* One iteration of the driver loop (abstract_pathtracer.cpp:38-112): global samples
+ * [iteration * spi, (iteration + 1) * spi) of every pixel, split over the members, reduced to
+ * member 0 and folded into its running-mean image.  Synchronises. */
+int ptk_group_render_iteration(ptk_group* group, uint64_t seed, uint64_t iteration,
+                               uint64_t samples_per_iteration);
+/* Member 0's running-mean image -> host (width*height*3 floats, row 0 = top). */
+int ptk_group_read_image(ptk_group* group, float* image_rgb);
+/* Sum of the members' counters. */
+int ptk_group_get_counters(ptk_group* group, ptk_counters* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,6 +154,17 @@ SYMBOLS = {
     "ptk_dev_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]),
     "ptk_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ptk_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ptk_group_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "ptk_group_destroy": (None, [C.c_void_p]),
+    "ptk_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "ptk_group_size": (C.c_int, [C.c_void_p]),
+    "ptk_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ptk_group_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "ptk_group_scene_set_camera": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc)]),
+    "ptk_group_render_begin": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64]),
+    "ptk_group_render_iteration": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "ptk_group_read_image": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ptk_group_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "ptk_scene_kd_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(KdInfo)]),
 }
 

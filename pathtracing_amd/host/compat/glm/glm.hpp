@@ -84,6 +84,10 @@ inline vec3 operator/(const vec3& a, const vec3& b) { return { a.x / b.x, a.y / 
 inline vec3 operator*(const vec3& a, float s) { return { a.x * s, a.y * s, a.z * s }; }
 inline vec3 operator*(float s, const vec3& a) { return { s * a.x, s * a.y, s * a.z }; }
 inline vec3 operator/(const vec3& a, float s) { return { a.x / s, a.y / s, a.z / s }; }
+inline vec3 operator+(const vec3& a, float s) { return { a.x + s, a.y + s, a.z + s }; }
+inline vec3 operator+(float s, const vec3& a) { return { s + a.x, s + a.y, s + a.z }; }
+inline vec3 operator-(const vec3& a, float s) { return { a.x - s, a.y - s, a.z - s }; }
+inline vec3 operator-(float s, const vec3& a) { return { s - a.x, s - a.y, s - a.z }; }
 inline vec3 operator-(const vec3& a) { return { -a.x, -a.y, -a.z }; }
 inline bool operator==(const vec3& a, const vec3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 inline bool operator!=(const vec3& a, const vec3& b) { return !(a == b); }

@@ -20,6 +20,7 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include <glm/glm.hpp>
 #include <glm/ext.hpp>
@@ -28,6 +29,10 @@
 #include "scene_graph.hpp"
 
 namespace rt {
+
+namespace detail {
+struct device_session;
+}
 
 template <typename... Args>
 class event_emitter { // abstract_pathtracer.h:27-85
@@ -141,12 +146,25 @@ public:
     // Additive GPU controls (defaults reproduce the stock behaviour on device 0).
     struct device_options {
         int device = 0;                    // HIP device ordinal
+        std::vector<int> devices;          // non-empty: render on these devices together (ids may repeat); overrides `device`
         uint64_t seed = 0;                 // Philox key; same seed => same image
         uint64_t max_paths_per_launch = 0; // ray-queue capacity, 0 = library default (2^24)
+        bool keep_scene = true;            // keep the uploaded tables between run() calls (camera-only changes skip the upload)
     };
     device_options device;
+    // Additive: what the last run() did before its driver thread started.
+    struct run_info {
+        bool scene_reused = false; // the previous run()'s device tables were kept (same scene, maybe another camera)
+        double prepare_ms = 0.0;   // scene hashing + KD build + upload, or just the camera update
+    };
+    run_info last_run;
+
+    pathtracer();
+    ~pathtracer() override;
 
 private:
+    friend class abstract_pathtracer; // run() dispatches the built-in integrator to the GPU driver
+    std::shared_ptr<detail::device_session> m_session;
     static constexpr float s_epsilon = 1e-3f;
     glm::vec3 trace_recursive(const view_parameters& params, const ray& r, const scene& scene, uint32_t recursion);
 };

@@ -6,8 +6,10 @@
 #include "device_render.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -157,18 +159,90 @@ bool flatten(const scene& sc, flat_scene& out, std::string& err)
     return true;
 }
 
-struct device_run {
-    ptk_ctx* ctx = nullptr;
-    float* d_sum = nullptr;
-    float* d_image = nullptr;
-    ~device_run()
-    {
-        if (!ctx) return;
-        ptk_dev_free(ctx, d_sum);
-        ptk_dev_free(ctx, d_image);
-        ptk_ctx_destroy(ctx);
+// 64-bit content hash (4 interleaved multiply-xor lanes over 8-byte words): decides whether the tables a
+// previous run() uploaded can be kept.  Not cryptographic; a collision would reuse stale tables.
+uint64_t hash_bytes(const void* data, size_t bytes, uint64_t seed)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint64_t h[4] = { seed ^ 0x9E3779B97F4A7C15ull, seed ^ 0xC2B2AE3D27D4EB4Full, seed ^ 0x165667B19E3779F9ull, seed ^ 0x27D4EB2F165667C5ull };
+    auto mix = [](uint64_t a, uint64_t w) {
+        a = (a ^ w) * 0xFF51AFD7ED558CCDull;
+        return a ^ (a >> 32);
+    };
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        for (int k = 0; k < 4; ++k) h[k] = mix(h[k], w[k]);
     }
-};
+    for (; i < bytes; ++i) h[i & 3] = mix(h[i & 3], p[i]);
+    uint64_t r = bytes;
+    for (int k = 0; k < 4; ++k) r = mix(r, h[k]);
+    return r;
+}
+
+// Everything of an rt::scene that ends up in the device tables, except the camera: node matrices and
+// material wiring, each mesh's identity (object_id, scene.h:194-201), triangle count and vertex data, sampler
+// colours, texture pixels, background.  Walks the scene graph directly (no packed copies are made).
+bool scene_key(const scene& sc, uint64_t& key)
+{
+    uint64_t h = 0x5CE11E;
+    auto add = [&](const void* d, size_t n) { h = hash_bytes(d, n, h); };
+    auto add_image = [&](const image* img) {
+        const uint64_t dims[3] = { img->get_width(), img->get_height(), uint64_t(img->sample_mode) };
+        add(dims, sizeof(dims));
+        add(img->data(), img->get_width() * img->get_height() * sizeof(glm::vec3));
+    };
+    std::map<const void*, int> seen;
+    for (const std::shared_ptr<scene_node>& np : sc.nodes) {
+        const scene_node& n = *np;
+        add(glm::value_ptr(n.get_transform()), 64);
+        add(glm::value_ptr(n.get_inverse_transform()), 64);
+        add(glm::value_ptr(n.get_normal_transform()), 64);
+        if (const auto* m = dynamic_cast<const mesh*>(n.shape.get())) {
+            const uint64_t head[3] = { 1, m->id, m->get_triangles().size() };
+            add(head, sizeof(head));
+            if (seen.emplace(m, 0).second)
+                for (const triangle& t : m->get_triangles()) add(t.vertices.data(), sizeof(ptk_triangle));
+        } else if (dynamic_cast<const sphere*>(n.shape.get())) {
+            const uint64_t head = 2;
+            add(&head, sizeof(head));
+        } else {
+            return false;
+        }
+        for (const std::shared_ptr<sampler_2d>* sp : { &n.material.albedo, &n.material.emission, &n.material.roughness, &n.material.metallic }) {
+            const sampler_2d* s = sp->get();
+            if (!s) return false;
+            if (const auto* c = dynamic_cast<const color_sampler*>(s)) {
+                const glm::vec3 rgb = c->average();
+                add(&rgb, sizeof(rgb));
+            } else if (const auto* img = dynamic_cast<const image*>(s)) {
+                const uint64_t tag = 3;
+                add(&tag, sizeof(tag));
+                const bool first = seen.emplace(img, 0).second;
+                const void* id = img; // which nodes share an image is part of the wiring
+                add(&id, sizeof(id));
+                if (first) add_image(img);
+            } else {
+                return false;
+            }
+        }
+    }
+    if (const auto* c = dynamic_cast<const color_sampler*>(sc.background.get())) {
+        const glm::vec3 rgb = c->average();
+        add(&rgb, sizeof(rgb));
+    } else if (const auto* eq = dynamic_cast<const equirectangular_map*>(sc.background.get())) {
+        const image* img = eq->get_image().get();
+        if (!img) return false;
+        const uint64_t tag = 4;
+        add(&tag, sizeof(tag));
+        add_image(img);
+    } else {
+        return false;
+    }
+    key = h;
+    return true;
+}
 
 std::shared_ptr<pathtracer_result> failed_run(const view_parameters& view, const std::string& why)
 {
@@ -182,75 +256,109 @@ std::shared_ptr<pathtracer_result> failed_run(const view_parameters& view, const
 
 } // namespace
 
-std::shared_ptr<pathtracer_result> run_on_device(const view_parameters& view, const trace_parameters& params,
-                                                 scene& sc, int device, uint64_t seed, uint64_t max_paths)
-{
-    auto run = std::make_shared<device_run>();
+// The device side of one rt::pathtracer, kept across run() calls: the group of contexts (one per device) and
+// the key of the scene whose tables they hold.  Sandbox calls run() again on every camera move
+// (rtsb.cpp:295-299,355); the reference recompiles the scene each time (abstract_pathtracer.cpp:13), here a
+// run whose scene key is unchanged only sends the camera (ptk_group_scene_set_camera): no KD build, no upload.
+struct device_session {
+    std::atomic<bool> busy{ false }; // set by the run that uses the session, from run() until its driver thread ends
+    ptk_group* group = nullptr;
+    std::vector<int> devices;
+    bool has_scene = false;
+    uint64_t key = 0;
+    ~device_session()
     {
+        if (group) ptk_group_destroy(group);
+    }
+};
+
+std::shared_ptr<device_session> make_device_session() { return std::make_shared<device_session>(); }
+
+std::shared_ptr<pathtracer_result> run_on_device(const view_parameters& view, const trace_parameters& params, scene& sc,
+                                                 const std::vector<int>& devices, uint64_t seed, uint64_t max_paths,
+                                                 std::shared_ptr<device_session> session, device_run_info* info)
+{
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    // a session that is still rendering (run() called again without wait()) is left alone: this run gets its own
+    if (!session || session->busy.exchange(true)) {
+        session = std::make_shared<device_session>();
+        session->busy = true;
+    }
+    // clears the flag when the last holder (this function on an early return, else the driver thread) lets go
+    std::shared_ptr<void> held(nullptr, [session](void*) { session->busy = false; });
+    if (info) *info = device_run_info{};
+
+    uint64_t key = 0;
+    if (!scene_key(sc, key)) {
+        flat_scene probe;
+        std::string err;
+        flatten(sc, probe, err); // for its message
+        return failed_run(view, err.empty() ? "scene cannot be rendered on the GPU" : err);
+    }
+    if (session->group && session->devices != devices) {
+        ptk_group_destroy(session->group);
+        session->group = nullptr;
+        session->has_scene = false;
+    }
+    if (!session->group) {
+        if (ptk_group_create(devices.data(), int(devices.size()), &session->group) != PTK_OK) {
+            session->group = nullptr;
+            return failed_run(view, ptk_group_last_error(nullptr));
+        }
+        session->devices = devices;
+    }
+    ptk_group* group = session->group;
+    if (session->has_scene && session->key == key) {
+        ptk_camera_desc cam{};
+        const glm::vec3& dir = sc.camera.get_direction();
+        cam.position[0] = sc.camera.position.x; cam.position[1] = sc.camera.position.y; cam.position[2] = sc.camera.position.z;
+        cam.direction[0] = dir.x; cam.direction[1] = dir.y; cam.direction[2] = dir.z;
+        if (ptk_group_scene_set_camera(group, &cam) != PTK_OK) return failed_run(view, ptk_group_last_error(group));
+        if (info) info->scene_reused = true;
+    } else {
         flat_scene flat;
         std::string err;
         if (!flatten(sc, flat, err)) return failed_run(view, err);
-        if (ptk_ctx_create(device, &run->ctx) != PTK_OK) return failed_run(view, ptk_last_error(nullptr));
-        if (ptk_scene_upload(run->ctx, &flat.desc) != PTK_OK) return failed_run(view, ptk_last_error(run->ctx));
+        session->has_scene = false;
+        if (ptk_group_scene_upload(group, &flat.desc) != PTK_OK) return failed_run(view, ptk_group_last_error(group));
+        session->has_scene = true;
+        session->key = key;
     } // host copies are released: the library keeps its own tables in HBM
+    if (info) info->prepare_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
 
-    return std::make_shared<pathtracer_result>([run, view, params, seed, max_paths](pathtracer_result& self) {
-        ptk_ctx* ctx = run->ctx;
+    // `held` travels with the driver thread's closure: the session is free again when the run is over
+    return std::make_shared<pathtracer_result>([session, held, group, view, params, seed, max_paths](pathtracer_result& self) mutable {
         image frame(view.width, view.height);
         const uint64_t num_pixels = uint64_t(view.width) * view.height;
-        const uint64_t frame_bytes = num_pixels * 3 * sizeof(float);
         auto ok = [&](int rc) {
             if (rc == PTK_OK) return true;
-            self.set_error(ptk_last_error(ctx));
-            std::fprintf(stderr, "[rt] GPU render failed: %s\n", ptk_last_error(ctx));
+            self.set_error(ptk_group_last_error(group));
+            std::fprintf(stderr, "[rt] GPU render failed: %s\n", ptk_group_last_error(group));
             return false;
         };
-        bool healthy = num_pixels > 0 && ok(ptk_render_begin(ctx, view.width, view.height, view.fov_y, max_paths)) &&
-                       ok(ptk_dev_alloc(ctx, frame_bytes, reinterpret_cast<void**>(&run->d_sum))) &&
-                       ok(ptk_dev_alloc(ctx, frame_bytes, reinterpret_cast<void**>(&run->d_image))) &&
-                       ok(ptk_dev_memset(ctx, run->d_sum, 0, frame_bytes)) &&
-                       ok(ptk_dev_memset(ctx, run->d_image, 0, frame_bytes));
-
+        bool healthy = num_pixels > 0 && ok(ptk_group_render_begin(group, view.width, view.height, view.fov_y, max_paths));
         const uint64_t spi = params.samples_per_iteration;
-        const uint64_t queue = max_paths ? max_paths : (1ull << 24);
-        // One slice = the pixels whose samples fill the ray queue once; progress and the
-        // interrupt flag are looked at between slices (the reference does so per scan line).
-        const uint64_t slice_pixels = std::max<uint64_t>(1, spi ? queue / std::min<uint64_t>(spi, queue) : num_pixels);
-
         for (uint64_t it = 0; healthy && (params.iterations == 0 || it < params.iterations) && !self.is_interrupted(); ++it) {
             self.on_iteration_start(it);
-            bool complete = true;
-            for (uint64_t p0 = 0; healthy && p0 < num_pixels; p0 += slice_pixels) {
-                if (self.is_interrupted()) {
-                    complete = false;
-                    break;
-                }
-                self.progress = float(p0) / float(num_pixels);
-                const uint64_t np = std::min(slice_pixels, num_pixels - p0);
-                // sample indices are global: iteration `it` owns [it*spi, (it+1)*spi)
-                for (uint64_t s0 = 0; healthy && s0 < spi; s0 += 0x40000000ull) {
-                    const uint32_t ns = uint32_t(std::min<uint64_t>(0x40000000ull, spi - s0));
-                    healthy = ok(ptk_render_samples_dev(ctx, seed, p0, np, it * spi + s0, ns, run->d_sum, s0 ? 1 : 0));
-                }
-                healthy = healthy && ok(ptk_ctx_synchronize(ctx));
-            }
-            if (!healthy) break;
-            // An iteration cut short by interrupt() leaves the image as it was; the events
-            // below still fire, as in abstract_pathtracer.cpp:105-109.
-            if (complete && spi > 0) healthy = ok(ptk_resolve_iteration_dev(ctx, run->d_sum, run->d_image, spi, it));
-            healthy = healthy && ok(ptk_dev_download(ctx, frame.data(), run->d_image, frame_bytes));
+            // One iteration is one call: the interrupt flag is looked at between iterations (the reference looks
+            // per scan line; an iteration is milliseconds here).  spi == 0 traces nothing, like the reference's
+            // empty sample loop, and leaves the image as it is.
+            if (spi > 0) healthy = ok(ptk_group_render_iteration(group, seed, it, spi));
+            healthy = healthy && ok(ptk_group_read_image(group, reinterpret_cast<float*>(frame.data())));
             ptk_counters counters{};
-            if (healthy && ptk_get_counters(ctx, &counters) == PTK_OK) {
+            if (healthy && ptk_group_get_counters(group, &counters) == PTK_OK) {
                 self.paths_traced = counters.paths;
                 self.rays_cast = counters.rays;
             }
             if (!healthy) break;
-            self.progress = complete ? 1.0f : self.progress.load();
+            self.progress = 1.0f;
             self.iteration = it;
             self.samples_per_pixel += spi;
             self.on_iteration_end(frame, it);
         }
         self.on_end(frame);
+        held.reset();
     });
 }
 

@@ -64,6 +64,9 @@ glm::vec3 rng::hemisphere(const glm::vec3& n) // rng.cpp:12-36: uniform, pdf 1/2
 // that callers and subclasses may invoke for individual rays.  run() never calls it for
 // an rt::pathtracer: images are produced by k_bounce on the GPU.
 
+pathtracer::pathtracer() = default;
+pathtracer::~pathtracer() = default;
+
 glm::vec3 pathtracer::trace(const view_parameters& params, const ray& r, const scene& scene)
 {
     return trace_recursive(params, r, scene, 5);
@@ -154,9 +157,15 @@ std::shared_ptr<pathtracer_result> abstract_pathtracer::run(const view_parameter
     if (typeid(*this) == typeid(pathtracer)) {
         // The built-in integrator: flatten + upload here (the work scene.compile() stands
         // for), render on the GPU from a driver thread.  No host rendering path exists.
-        const pathtracer& self = static_cast<const pathtracer&>(*this);
-        return detail::run_on_device(view_params, trace_params, scene, self.device.device, self.device.seed,
-                                     self.device.max_paths_per_launch);
+        pathtracer& self = static_cast<pathtracer&>(*this);
+        const std::vector<int> devices = self.device.devices.empty() ? std::vector<int>{ self.device.device } : self.device.devices;
+        if (self.device.keep_scene && !self.m_session) self.m_session = detail::make_device_session();
+        detail::device_run_info info;
+        auto result = detail::run_on_device(view_params, trace_params, scene, devices, self.device.seed, self.device.max_paths_per_launch,
+                                            self.device.keep_scene ? self.m_session : nullptr, &info);
+        self.last_run.scene_reused = info.scene_reused;
+        self.last_run.prepare_ms = info.prepare_ms;
+        return result;
     }
     return std::make_shared<pathtracer_result>([this, view_params, trace_params, &scene](pathtracer_result& self) {
         host_driver(*this, view_params, trace_params, scene, self);

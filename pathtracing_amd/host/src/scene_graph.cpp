@@ -134,9 +134,10 @@ kd_tree_node::kd_tree_node(const std::vector<triangle>& triangles, const boundin
     if (!acc.nodes.empty()) assign_from_flat(acc, triangles, 0);
 }
 
-// Pointer-tree view of the flattened subtree rooted at slot `at`: a node's left child is
-// the next preorder slot, its right child starts where the left subtree's skip link points
-// (both children always exist: the mean split has a vertex on either side, scene.cpp:257-265).
+// Pointer-tree view of the flattened subtree rooted at slot `at`: the first child is the next preorder slot, a
+// second child starts where the first one's skip link points.  A lone child (scene.cpp:280-284 makes a child only
+// for a non-empty side) is the left one if it kept the parent's min on the split axis, else the right one
+// (bounding_box::split, scene.cpp:31-56).
 void kd_tree_node::assign_from_flat(const mesh_accel& acc, const std::vector<triangle>& tris, size_t at)
 {
     const ptk_kd_node& n = acc.nodes[at];
@@ -147,14 +148,17 @@ void kd_tree_node::assign_from_flat(const mesh_accel& acc, const std::vector<tri
     for (uint32_t k = 0; k < n.num_prims; ++k) m_triangles.push_back(tris[acc.prims[n.first_prim + k]]);
     m_left.reset();
     m_right.reset();
-    size_t child = at + 1;
-    if (n.num_prims != 0 || child >= n.skip) return; // leaf
-    m_left = std::make_unique<kd_tree_node>();
-    m_left->assign_from_flat(acc, tris, child);
-    child = acc.nodes[child].skip;
-    if (child < n.skip) {
+    const size_t first = at + 1;
+    if (n.num_prims != 0 || first >= n.skip) return; // leaf
+    const size_t second = acc.nodes[first].skip;
+    const uint32_t axis = n.depth % 3u;
+    const bool lone_right = second >= n.skip && std::memcmp(&acc.nodes[first].bmin[axis], &n.bmin[axis], sizeof(float)) != 0;
+    std::unique_ptr<kd_tree_node>& slot = lone_right ? m_right : m_left;
+    slot = std::make_unique<kd_tree_node>();
+    slot->assign_from_flat(acc, tris, first);
+    if (second < n.skip) {
         m_right = std::make_unique<kd_tree_node>();
-        m_right->assign_from_flat(acc, tris, child);
+        m_right->assign_from_flat(acc, tris, second);
     }
 }
 

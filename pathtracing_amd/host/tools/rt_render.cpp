@@ -4,24 +4,31 @@
 // (translate -> multiply(Rz*Ry*Rx) -> scale; shared meshes and samplers), call
 // rt::pathtracer::run, subscribe to the events, wait(), save the result.
 //
-// Input is a small token stream ("ptkscene 1", written by tests/host_scene_text.py from
-// the same scene objects the Python tests use) rather than the reference's JSON + OBJ
-// files: those loaders are callers of the path, not part of it.
+// Input is either the reference's own scene JSON (a file name ending in .json: read by
+// rt::utility::load_scene with its OBJ meshes and stb-decoded textures, asset paths relative to
+// --asset-root as they are relative to the working directory in the reference) or a small
+// token stream ("ptkscene 1", written by tests/host_scene_text.py from the same scene objects
+// the Python tests use).
 //
 //   rt_render --scene S --out image.bin [--resolution W H]
-//             [--iterations N] [--spp-per-iteration K] [--seed X] [--device D] [--threads T]
-//             [--ldr-out rgba8.bin] [--interrupt-after N]
+//             [--iterations N] [--spp-per-iteration K] [--seed X] [--device D | --devices D0,D1,..]
+//             [--threads T] [--ldr-out rgba8.bin] [--interrupt-after N] [--asset-root DIR]
+//             [--then-camera PX PY PZ DX DY DZ --then-out image2.bin]   (a second run() on the same
+//              rt::pathtracer with only the camera moved: the Sandbox pattern, rtsb.cpp:295-299,355)
 //
 // image.bin: W*H*3 little-endian floats, row 0 = top (linear HDR, before the CLI tone map).
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
 
 #include <pathtracer.h>
+#include <scene_loader.h>
+#include <unistd.h>
 
 namespace {
 
@@ -151,7 +158,10 @@ int main(int argc, char** argv)
     uint32_t threads = 4;
     uint64_t interrupt_after = 0; // > 0: call interrupt() from the on_iteration_end handler (Sandbox-style stop)
     int device = 0;
-    std::string scene_file, out_file = "result.bin", ldr_file;
+    std::vector<int> devices;
+    std::string scene_file, out_file = "result.bin", ldr_file, asset_root, then_out;
+    bool then_camera = false;
+    glm::vec3 then_pos(0.0f), then_dir(0.0f, 0.0f, -1.0f);
     for (int i = 1; i < argc; ++i) {
         const std::string p = argv[i];
         auto need = [&](int n) { return i + n < argc; };
@@ -164,6 +174,20 @@ int main(int argc, char** argv)
         else if (p == "--seed" && need(1)) seed = std::stoull(argv[++i]);
         else if (p == "--device" && need(1)) device = std::stoi(argv[++i]);
         else if (p == "--interrupt-after" && need(1)) interrupt_after = std::stoull(argv[++i]);
+        else if (p == "--asset-root" && need(1)) asset_root = argv[++i];
+        else if (p == "--then-out" && need(1)) then_out = argv[++i];
+        else if (p == "--devices" && need(1)) {
+            const std::string list = argv[++i];
+            for (size_t a = 0; a <= list.size();) {
+                const size_t b = std::min(list.find(',', a), list.size());
+                if (b > a) devices.push_back(std::stoi(list.substr(a, b - a)));
+                a = b + 1;
+            }
+        } else if (p == "--then-camera" && need(6)) {
+            then_camera = true;
+            for (int k = 0; k < 3; ++k) then_pos[k] = std::strtof(argv[++i], nullptr);
+            for (int k = 0; k < 3; ++k) then_dir[k] = std::strtof(argv[++i], nullptr);
+        }
         else if (p == "--resolution" && need(2)) {
             width = uint32_t(std::stoul(argv[++i]));
             height = uint32_t(std::stoul(argv[++i]));
@@ -174,10 +198,25 @@ int main(int argc, char** argv)
     }
 
     rt::scene scene;
-    if (!load_scene_text(scene_file, scene)) return 1;
+    if (scene_file.size() > 5 && scene_file.substr(scene_file.size() - 5) == ".json") {
+        // the reference resolves asset paths against the working directory (premake5.lua:170-172)
+        char cwd[4096];
+        if (!getcwd(cwd, sizeof(cwd))) return 1;
+        auto absolute = [&](const std::string& f) { return f.empty() || f[0] == '/' ? f : std::string(cwd) + "/" + f; };
+        scene_file = absolute(scene_file);
+        out_file = absolute(out_file);
+        ldr_file = absolute(ldr_file);
+        then_out = absolute(then_out);
+        if (!asset_root.empty() && chdir(asset_root.c_str()) != 0) return fail("cannot enter " + asset_root) ? 1 : 1;
+        scene = rt::utility::load_scene(scene_file);
+        if (scene.nodes.empty()) return fail("no nodes in " + scene_file) ? 1 : 1;
+    } else if (!load_scene_text(scene_file, scene)) {
+        return 1;
+    }
 
     rt::pathtracer pathtracer;
     pathtracer.device.device = device;
+    pathtracer.device.devices = devices;
     pathtracer.device.seed = seed;
     rt::view_parameters view_params;
     rt::trace_parameters trace_params;
@@ -221,6 +260,25 @@ int main(int argc, char** argv)
     if (!result->error().empty()) {
         std::fprintf(stderr, "rt_render: %s\n", result->error().c_str());
         return 2;
+    }
+    const double first_prepare_ms = pathtracer.last_run.prepare_ms;
+    if (then_camera) {
+        // Sandbox: the camera moved, run() again on the same pathtracer and scene objects
+        scene.camera.position = then_pos;
+        scene.camera.set_direction(then_dir);
+        auto again = pathtracer.run(view_params, trace_params, scene);
+        again->on_end.subscribe([&](const rt::image& image) {
+            if (then_out.empty()) return;
+            std::ofstream out(then_out, std::ios::binary);
+            out.write(reinterpret_cast<const char*>(image.data()), std::streamsize(image.get_width() * image.get_height() * 12));
+        });
+        again->wait();
+        if (!again->error().empty()) {
+            std::fprintf(stderr, "rt_render: %s\n", again->error().c_str());
+            return 2;
+        }
+        std::printf("second run: reused=%d prepare_ms=%.3f first_prepare_ms=%.3f\n", pathtracer.last_run.scene_reused ? 1 : 0,
+                    pathtracer.last_run.prepare_ms, first_prepare_ms);
     }
     std::printf("done: iteration=%" PRIu64 " spp=%" PRIu64 " paths=%" PRIu64 " rays=%" PRIu64 " events=%" PRIu64 "/%" PRIu64 "\n",
                 result->iteration.load(), result->samples_per_pixel.load(), result->paths_traced.load(),

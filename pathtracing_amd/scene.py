@@ -98,20 +98,56 @@ def _decode_rgbe(path):
     return rgb.astype(np.float32)
 
 
-def load_image(path):
-    """image::load, sampler.cpp:78-96: stbi_loadf(..., 3) with vertical flip.  8-bit
-    sources are linearised like stb (pow(v/255, 2.2), stb_image.h:1799-1811); .hdr is
-    RGBE float.  JPEG decoding uses PIL (the reference uses stb's decoder; texel values
-    may differ by a level or two — they are inputs of the hot path, not part of it)."""
-    if path.lower().endswith(".hdr"):
-        px = _decode_rgbe(path)
-    else:
-        from PIL import Image as PILImage
+_HOST_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
 
-        u8 = np.asarray(PILImage.open(path).convert("RGB"), dtype=np.uint8)
-        lin = np.power((u8.astype(np.float32) / np.float32(255.0)).astype(np.float64), float(np.float32(2.2)))
-        px = lin.astype(np.float32)
+
+def _read_pfm(path):
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"PF":
+            raise ValueError(f"{path}: not a colour PFM")
+        w, h = (int(x) for x in f.readline().split())
+        scale = float(f.readline())
+        px = np.frombuffer(f.read(), dtype="<f4" if scale < 0 else ">f4").reshape(h, w, 3)
+    return px.astype(np.float32)
+
+
+def load_image(path, decoder="auto"):
+    """image::load, sampler.cpp:78-96: stbi_loadf(..., 3) with vertical flip.  8-bit sources are linearised
+    like stb (pow(v/255, 2.2), stb_image.h:1799-1811); .hdr is RGBE float (decoded here, bit-identical to stb's).
+    JPEG / PNG go through the host library's own image::load (pathtracing_amd/host/rt_ingest, built with the
+    stb_image.h the reference vendors), so the harness sees the texels the reference's loader produces;
+    decoder="pil" forces the PIL decoder (texels may differ by a level or two: a different IDCT), which is also
+    what "auto" falls back to when the host tool has not been built."""
+    if path.lower().endswith(".hdr"):
+        return Image(_decode_rgbe(path)[::-1].copy())
+    tool = os.path.join(_HOST_DIR, "rt_ingest")
+    if decoder == "auto" and os.path.exists(tool):
+        import subprocess
+        import tempfile
+
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "image.pfm")
+            run = subprocess.run([tool, "image", path, out], capture_output=True, text=True)
+            if run.returncode == 0:
+                return Image(_read_pfm(out))  # already bottom-up, as image::load stores it
+    from PIL import Image as PILImage
+
+    u8 = np.asarray(PILImage.open(path).convert("RGB"), dtype=np.uint8)
+    lin = np.power((u8.astype(np.float32) / np.float32(255.0)).astype(np.float64), float(np.float32(2.2)))
+    px = lin.astype(np.float32)
     return Image(px[::-1].copy())
+
+
+_STOF = re.compile(r"-?(\d+\.?\d*|\.\d+)")
+
+
+def _stof(text):
+    """std::stof on a token of the grammar -?[\\d.]+: the longest prefix that is a number ("2.5.7" -> 2.5);
+    no number at all (".", "-.") raises, as std::stof throws."""
+    m = _STOF.match(text)
+    if not m:
+        raise ValueError(f"stof: no conversion for {text!r}")
+    return float(m.group(0))
 
 
 def load_meshes_from_wavefront(path):
@@ -142,15 +178,15 @@ def load_meshes_from_wavefront(path):
         for line in f.read().split("\n"):
             m = r_vertex.search(line)
             if m:
-                vs.append([float(m.group(i)) for i in (1, 2, 3)])
+                vs.append([_stof(m.group(i)) for i in (1, 2, 3)])
                 continue
             m = r_normal.search(line)
             if m:
-                ns.append([float(m.group(i)) for i in (1, 2, 3)])
+                ns.append([_stof(m.group(i)) for i in (1, 2, 3)])
                 continue
             m = r_uv.search(line)
             if m:
-                ts.append([float(m.group(i)) for i in (1, 2)])
+                ts.append([_stof(m.group(i)) for i in (1, 2)])
                 continue
             m = r_face0.search(line)
             if m:

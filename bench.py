@@ -47,6 +47,8 @@ def load_workload(name, triangles):
     return workloads.synthetic_scene(triangles, 4096, bg)
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
+PEAK_L2_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 (8 XCDs x 4 MiB)
+PTK_DEPTH = 5              # pathtracer.cpp:16
 
 
 def load_pmc_traffic(workload):
@@ -130,8 +132,8 @@ def cpu_baseline(scene, workload, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU port for workloads other than room")
     ap.add_argument("--traversal", type=int, default=None, help="PTK_OPT_TRAVERSAL override (0/1), for A/B runs")
@@ -261,6 +263,14 @@ def main():
                        "parallelism": f"sample-range x{world}" + (" + RCCL reduce(sum) to rank 0" if distributed else "")},
         }
         model = None
+        model_tables = {"kd_bytes": 0}
+        for m in range(64):   # tree tables of the uploaded scene: 64-B nodes, 64-B hit records + 8 B of indices per leaf slot
+            try:
+                ki = ctx.kd_info(m)
+            except Exception:
+                break
+            if ki.num_nodes > 1:
+                model_tables["kd_bytes"] += 64 * ki.num_nodes + 72 * ki.num_leaf_prims
         if not args.no_cpu_baseline and (args.workload == "room" or args.cpu_baseline):
             # the timed CPU baseline is an N = 1 figure; with more ranks only a short sample runs, for the
             # operation counts the roofline needs
@@ -276,45 +286,68 @@ def main():
         nw, msw = timing["k_walk"]
         nsp, mssp = timing["k_shade_parked"]
         pmc = load_pmc_traffic(args.workload)
-        if n_launch and model is not None:
+        if n_launch and model is not None and not nw:
+            # Room / materials: the whole scene is cache resident, HBM sees the ray queue only -> VALU-bound.
             rays_next = (rays - paths) / world / n_launch          # rays cast per k_bounce<false> launch
             avg_ms = ms / n_launch
             tflops = model["flops_per_ray"] * rays_next / (avg_ms * 1e-3) / 1e12
-            gbs = model["bytes_per_ray"] * rays_next / (avg_ms * 1e-3) / 1e9
-            common = {"kernel": "k_bounce<false>", "traffic": pmc.get("k_bounce<false>"), "traffic_source": pmc.get("source"),
-                      "avg_launch_ms": avg_ms, "launches": n_launch,
-                      "rays_per_launch": rays_next, "first_bounce_avg_ms": (ms0 / n0) if n0 else None, **model}
-            if nw:
-                # split mode: one bounce = k_bounce_split (spheres, one-leaf meshes, parking) + k_walk (KD-trees
-                # of the parked rays) + k_shade_parked.  k_walk's algorithmic bytes: the KD nodes and triangle
-                # records of the pruned walk (64 B each) + the parked record in and out (76 + 36 B per ray).
-                rays_launch = rays / world / nw
-                walk_ms = msw / nw
-                walk_bytes = (64 * model["kd_nodes_per_ray"] + 64 * model["triangles_per_ray"] + 112) * rays_launch
-                bounce_ms = (ms + ms0 + msw + mssp) / nw
-                common.update({"kernel": "k_walk", "traffic": pmc.get("k_walk"), "avg_launch_ms": walk_ms, "launches": nw,
-                               "rays_per_launch": rays_launch,
-                               "bounce_kernels_avg_ms": {"k_bounce_split": (ms + ms0) / (n_launch + n0), "k_walk": walk_ms,
-                                                         "k_shade_parked": mssp / nsp if nsp else None},
-                               "bounce_algorithmic_GBs": model["bytes_per_ray"] * rays_launch / (bounce_ms * 1e-3) / 1e9})
-                gbs = walk_bytes / (walk_ms * 1e-3) / 1e9
-                tflops = model["flops_per_ray"] * rays_launch / (bounce_ms * 1e-3) / 1e12
-            measured = (common["traffic"] / (common["avg_launch_ms"] * 1e-3) / 1e9) if common.get("traffic") else None
-            note = ("no MFMA on this path; peak = fp32 vector FMA peak with packed issue, while hit arithmetic is built "
-                    "unfused (-ffp-contract=off, bit-exact ids) so 78.6 T un-fused op/s is the reachable ceiling; flops are "
-                    "the REFERENCE's operation count per ray (it tests every node and walks every box-hit KD node), the "
-                    "kernels' conservative cull and pruned walk skip most of them; VALU issue is the measured limiter "
-                    "(valu_busy_frac in profiles/*_pmc.json)")
-            if nw:
-                note += ("; split mode: achieved = flops per ray x rays per bounce over the three kernels of a bounce, "
-                         "kernel / avg_launch_ms / traffic are the walker's; hbm_algorithmic_GBs counts 64 B per KD node / "
-                         "triangle the pruned walk touches, mostly L2 / Infinity Cache hits (hbm_measured_* is PMC traffic)")
+            # algorithmic HBM bytes of one launch: every ray is read (52 B); a survivor is written back (52 B), a path
+            # that ends writes its radiance (12 B).  Survivors of launch b = rays of launch b + 1 (0 after the last).
+            rays_in = (rays - paths) / world                        # all k_bounce<false> launches together
+            paths_w = paths / world
+            # rays entering bounces 2..4 are the survivors written by bounces 1..3; bounce 0's survivors (= rays of
+            # bounce 1) are written by k_bounce<true>, not by this kernel
+            queue_bytes = (52.0 * rays_in + 52.0 * max(0.0, rays_in - rays_in / (PTK_DEPTH - 1)) + 12.0 * paths_w) / n_launch
+            gbs = queue_bytes / (avg_ms * 1e-3) / 1e9
+            measured = (pmc["k_bounce<false>"] / (avg_ms * 1e-3) / 1e9) if pmc.get("k_bounce<false>") else None
             out["roofline"] = {
-                "bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / PEAK_FP32_TFLOPS, **common,
-                "hbm_algorithmic_GBs": gbs, "hbm_measured_GBs": measured,
+                "bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
+                "kernel": "k_bounce<false>", "traffic": pmc.get("k_bounce<false>"), "traffic_source": pmc.get("source"),
+                "avg_launch_ms": avg_ms, "launches": n_launch, "rays_per_launch": rays_next,
+                "first_bounce_avg_ms": (ms0 / n0) if n0 else None,
+                "flops_per_ray": model["flops_per_ray"],
+                "hbm_algorithmic_bytes_per_launch": queue_bytes, "hbm_algorithmic_GBs": gbs, "hbm_measured_GBs": measured,
                 "hbm_measured_frac": (measured / PEAK_HBM_GBS) if measured else None, "hbm_peak_GBs": PEAK_HBM_GBS,
-                "note": note,
+                "note": ("no MFMA on this path (nothing is a dense contraction); the scene tables (a few KB) are cache resident, so HBM "
+                         "carries the ray queue only (hbm_algorithmic_*: 52 B per ray read, 52 B per survivor or 12 B per ended path "
+                         "written; an estimate from the counters: survivors of a launch = rays of the next) and the kernel is bound by "
+                         "VALU issue.  peak = fp32 vector peak with packed FMA; hit arithmetic is built unfused "
+                         "(-ffp-contract=off, bit-exact ids), so 78.6 T op/s is the reachable ceiling.  flops = the REFERENCE's "
+                         "operation count per ray (it tests every node; tests/golden/flop_costs.json x the oracle's counts); the "
+                         "kernel's conservative cull skips most of that work, valu_busy_frac is in profiles/*_pmc.json"),
+            }
+        elif nw and model is not None:
+            # Scenes with KD-trees (Mario, config 5): one bounce = k_bounce_split (spheres, one-leaf meshes, parking) +
+            # k_walk (KD-trees of the parked rays) + k_shade_parked; k_walk dominates.  SURVEY 8d: HBM-bound line from
+            # the build's own pruned walk (V nodes, T triangles per ray: oracle walk model 1).
+            rays_launch = rays / world / nw
+            walk_ms = msw / nw
+            V, T = model["kd_nodes_per_ray"], model["triangles_per_ray"]
+            touched = (64.0 * V + 64.0 * T) * rays_launch          # bytes the walk requests (mostly cache hits)
+            tables = float(model_tables["kd_bytes"])               # what HBM must deliver at least once per launch ...
+            parked = 112.0 * rays_launch                            # ... plus the parked record in (76 B) and out (36 B)
+            compulsory = min(touched, tables) + parked
+            traffic = pmc.get("k_walk")
+            out["roofline"] = {
+                "bound": "hbm", "achieved": compulsory / (walk_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": compulsory / (walk_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "kernel": "k_walk", "traffic": traffic, "traffic_source": pmc.get("source"),
+                "avg_launch_ms": walk_ms, "launches": nw, "rays_per_launch": rays_launch,
+                "kd_nodes_per_ray": V, "triangles_per_ray": T, "texels_per_ray": model["texels_per_ray"],
+                "ref_kd_nodes_per_ray": model["ref_kd_nodes_per_ray"], "ref_triangles_per_ray": model["ref_triangles_per_ray"],
+                "algorithmic_bytes_per_launch": compulsory, "tree_table_bytes": tables,
+                "requested_bytes_per_launch": touched, "requested_GBs": touched / (walk_ms * 1e-3) / 1e9,
+                "requested_frac_of_l2_peak": touched / (walk_ms * 1e-3) / 1e9 / PEAK_L2_GBS, "l2_peak_GBs": PEAK_L2_GBS,
+                "hbm_measured_GBs": (traffic / (walk_ms * 1e-3) / 1e9) if traffic else None,
+                "bounce_kernels_avg_ms": {"k_bounce_split": (ms + ms0) / max(1, n_launch + n0), "k_walk": walk_ms,
+                                          "k_shade_parked": mssp / nsp if nsp else None},
+                "note": ("achieved = algorithmic HBM bytes per k_walk launch / its average duration.  Algorithmic bytes = what HBM has to "
+                         "deliver at least once: min(bytes the pruned walk requests = 64 B x (V nodes + T triangles) per ray, size of "
+                         "the tree tables) + the parked record in and out (112 B per ray).  requested_* is the walk's request stream, "
+                         "served mostly by L2 (34.5 TB/s aggregate) and the Infinity Cache; traffic = PMC HBM bytes per launch "
+                         "(profiles/): traffic / algorithmic > 1 = re-reads after cache eviction.  The walker is limited by the issue "
+                         "rate of its divergent walk (valu_busy_frac in profiles/*_pmc.json), not by HBM: see DESIGN.md.  ref_* = the "
+                         "reference's unpruned walk (every box-hit node), for comparison only"),
             }
         else:
             out["roofline"] = None

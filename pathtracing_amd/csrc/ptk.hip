@@ -524,8 +524,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     const uint64_t cap = Q.cap;
     const float* __restrict__ qin = Q.q[bounce & 1u];
 
-    uint32_t stack_i[kKdStack];
-    float stack_t[kKdStack];
+    WalkLds& my_lds = wave_lds[threadIdx.x >> 6];
+    const LdsStack stack{ &my_lds.stack_i[0][lane], &my_lds.stack_t[0][lane] };
+    const int stack_cap = (int)S.walk_stack < kWalkStack ? (int)S.walk_stack : kWalkStack;
     KdWalk W;
     walk_begin(W, S, DMesh{ 0u, 0u, 0u, 0u }, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), false);
     uint32_t state = IDLE;
@@ -535,12 +536,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     uint32_t mine = 0u, node = 0u; // parked record of the lane's ray, tree node being walked
     unsigned long long trees = 0ull;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
-    Hit best;
-    best.d0 = 3.402823466e+38f;
-    best.node = -1;
-    best.prim = -1;
-    best.a0 = best.a1 = best.a2 = 0.0f;
-    best.pw = mk(0.0f, 0.0f, 0.0f);
+    // The ray's best hit so far stays in its parked record (pend_best): a walk works in the node's local space
+    // and never looks at it; it is read and, if beaten, rewritten when a tree node's walk ends (FIN).
 
     for (;;) {
         // refill
@@ -576,14 +573,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
                     mine = seg_cur * kBlock + pos + mbcnt64(idle_left);
                     const uint32_t slot = Q.pend_slot[mine];
                     trees = Q.pend_mask[mine];
-                    const float* __restrict__ pb = Q.pend_best;
-                    best.d0 = pb[0 * cap + mine];
-                    best.node = __float_as_int(pb[1 * cap + mine]);
-                    best.prim = __float_as_int(pb[2 * cap + mine]);
-                    best.a0 = pb[3 * cap + mine];
-                    best.a1 = pb[4 * cap + mine];
-                    best.a2 = pb[5 * cap + mine];
-                    best.pw = mk(pb[6 * cap + mine], pb[7 * cap + mine], pb[8 * cap + mine]);
                     if (BATCH) {
                         o = mk(B.o[slot], B.o[B.n + slot], B.o[2 * B.n + slot]);
                         d = mk(B.d[slot], B.d[B.n + slot], B.d[2 * B.n + slot]);
@@ -608,7 +597,21 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
                     V3 pw;
                     float d0;
                     lane_hit_to_world(nv, o, W.p, pw, d0); // scene.cpp:375,383
-                    best_update(best, d0, (int)node, W.best_slot, W.bar, pw);
+                    // scene.cpp:386 with the node-order tie rule of best_update, against the parked record
+                    float* __restrict__ pb = Q.pend_best;
+                    const float bd0 = pb[0 * cap + mine];
+                    const int bnode = __float_as_int(pb[1 * cap + mine]);
+                    if (d0 < bd0 || (d0 == bd0 && (int)node < bnode)) {
+                        pb[0 * cap + mine] = d0;
+                        pb[1 * cap + mine] = __int_as_float((int)node);
+                        pb[2 * cap + mine] = __int_as_float(W.best_slot);
+                        pb[3 * cap + mine] = W.bar.x;
+                        pb[4 * cap + mine] = W.bar.y;
+                        pb[5 * cap + mine] = W.bar.z;
+                        pb[6 * cap + mine] = pw.x;
+                        pb[7 * cap + mine] = pw.y;
+                        pb[8 * cap + mine] = pw.z;
+                    }
                 }
                 state = START;
             }
@@ -649,15 +652,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             if (2u * n_node >= n_leaf && 2u * n_node >= 3u * n_pop) {
                 PTK_STAT(S, 22, 1);
                 PTK_STAT(S, 23, n_node);
-                if (at_node) walk_descend_step<true>(W, S, stack_i, stack_t);
+                if (at_node) walk_descend_step<true>(W, S, stack, stack_cap);
             } else if (3u * n_pop >= n_leaf) {
                 PTK_STAT(S, 29, 1);
                 PTK_STAT(S, 30, n_pop);
-                if (at_pop) walk_pop(W, stack_i, stack_t);
+                if (at_pop) walk_pop(W, stack);
             } else {
                 PTK_STAT(S, 26, 1);
                 PTK_STAT(S, 27, n_leaf);
-                walk_leaf_stage(W, S, at_leaf, wave_lds[threadIdx.x >> 6]);
+                walk_leaf_stage(W, S, at_leaf, my_lds);
                 if (at_leaf && W.leaf_done >= (W.cb & kKdCountMask)) {
                     W.leaf_done = 0u;
                     W.cur = kWalkPop;
@@ -665,21 +668,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             }
         }
 
-        // a ray that is through hands its best hit back to its parked record (k_shade_parked /
-        // k_batch_parked pick it up with every lane busy) and frees the lane
-        if (state == DONE) {
-            float* __restrict__ pb = Q.pend_best;
-            pb[0 * cap + mine] = best.d0;
-            pb[1 * cap + mine] = __int_as_float(best.node);
-            pb[2 * cap + mine] = __int_as_float(best.prim);
-            pb[3 * cap + mine] = best.a0;
-            pb[4 * cap + mine] = best.a1;
-            pb[5 * cap + mine] = best.a2;
-            pb[6 * cap + mine] = best.pw.x;
-            pb[7 * cap + mine] = best.pw.y;
-            pb[8 * cap + mine] = best.pw.z;
-            state = IDLE;
-        }
+        // a ray that is through frees its lane (its parked record already holds its best hit; k_shade_parked /
+        // k_batch_parked pick it up with every lane busy)
+        if (state == DONE) state = IDLE;
         if (dry && __builtin_amdgcn_ballot_w64(state != IDLE) == 0ull) break;
     }
 }
@@ -932,6 +923,7 @@ struct ptk_ctx {
     int balance = 2;   // PTK_OPT_BALANCE
     int split = 2;     // PTK_OPT_SPLIT
     int device_kd = 2; // PTK_OPT_DEVICE_KD
+    int walk_stack = 64; // PTK_OPT_WALK_STACK (clamped to the kernels' own capacity)
     uint32_t num_trees = 0; // nodes of class kClassTree
 
     // split mode (scenes with KD-trees): second ray queue, parked-ray list, counters
@@ -1986,6 +1978,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     S.cam_x = sc->camera.position[0];
     S.cam_y = sc->camera.position[1];
     S.cam_z = sc->camera.position[2];
+    S.walk_stack = (uint32_t)c->walk_stack;
 #ifdef PTK_STATS
     {
         void* sp = nullptr;
@@ -2398,6 +2391,11 @@ int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
     }
     if (option == PTK_OPT_DEVICE_KD && value >= 0 && value <= 2) {
         c->device_kd = value;
+        return PTK_OK;
+    }
+    if (option == PTK_OPT_WALK_STACK && value >= 0 && value <= 64) {
+        c->walk_stack = value;
+        c->S.walk_stack = (uint32_t)value;
         return PTK_OK;
     }
     if (option == PTK_OPT_KD_PRUNE && (value == 0 || value == 1)) {

@@ -133,6 +133,7 @@ struct DScene {
     float bg_r, bg_g, bg_b;
     uint32_t bg_texture, bg_mode;
     float cam_x, cam_y, cam_z;
+    uint32_t walk_stack; // pending far children a KD walk may hold before it sweeps a subtree without a stack (PTK_OPT_WALK_STACK)
 #ifdef PTK_STATS
     unsigned long long* stats; // experiment builds only: work counters of the balanced traversal
 #endif
@@ -365,8 +366,32 @@ __device__ __forceinline__ void kd_walk_reference(const DScene& S, const DMesh m
 //     strictly farther than the current best (margins below cover fp32 rounding of both the
 //     slab arithmetic and the hit distance), hence neither a winner nor a tie;
 //   * exact ties between visited candidates go to the lower slot (tri_test).
-// The stack holds one pending far child per level: depth <= PTK_KD_MAX_DEPTH.
-constexpr int kKdStack = (int)PTK_KD_MAX_DEPTH + 4;
+// The stack holds pending far children, one per level at most.  It is SHORT: the walker kernel keeps
+// kWalkStack entries per lane in LDS, the per-lane loops of the other kernels a small local array.  A walk
+// that needs more (chains of unsplittable triangles run the tree down to depth 100, scene.cpp:220) does not
+// spill: at the node where the stack is full it stops ordering children and sweeps that node's subtree in
+// preorder with the skip links ("box passes or leaf -> next slot, interior node fails -> its skip link"),
+// every node still subject to the reference's box test and to the distance pruning.  The sweep visits the
+// same leaves a stack would have reached, in another order, and the (distance, slot) rule makes the order
+// irrelevant; when it ends the walk pops its short stack as usual.
+constexpr int kWalkStack = 12;  // LDS entries per lane in k_walk (8 B each: 6 KB per wave)
+constexpr int kKdStack = 16;    // local entries of the closed per-lane loops (kd_walk_pruned)
+
+// Where a walk keeps its pending far children: (node index, lower bound of the squared hit distance below it).
+struct LocalStack {
+    uint32_t* idx;
+    float* bound;
+    __device__ __forceinline__ void put(int sp, uint32_t i, float b) const { idx[sp] = i; bound[sp] = b; }
+    __device__ __forceinline__ uint32_t node(int sp) const { return idx[sp]; }
+    __device__ __forceinline__ float dist(int sp) const { return bound[sp]; }
+};
+struct LdsStack { // entry e of lane l at [e * 64 + l]: lanes side by side, no bank conflicts
+    uint32_t* idx;
+    float* bound;
+    __device__ __forceinline__ void put(int sp, uint32_t i, float b) const { idx[sp * 64] = i; bound[sp * 64] = b; }
+    __device__ __forceinline__ uint32_t node(int sp) const { return idx[sp * 64]; }
+    __device__ __forceinline__ float dist(int sp) const { return bound[sp * 64]; }
+};
 
 // Returns true when the subtree under a node can be skipped; `bound` receives a lower bound
 // of the squared distance of any hit below it (0 when the origin may be inside the box).
@@ -406,7 +431,7 @@ struct KdWalk {
     uint32_t leaf_base;    // DMesh::leaf_base
     V3 o, d, inv;          // local ray, approximate reciprocal direction (pruning only)
     float oabs;
-    uint32_t neg;          // sign bits of d
+    uint32_t neg;          // bits 0-2: sign bits of d; bit 3: a stackless sweep is under way (next node in cr, end in cs)
     uint32_t cur, ca, cb, cr; // node being processed (kWalkNone = walk finished) and its header words
     float cs;
     float T1, T2, T3, T4, T5, T6; // its six slab quotients
@@ -436,13 +461,42 @@ __device__ __forceinline__ void walk_enter(KdWalk& W, uint32_t idx)
     W.T6 = (y.y - W.o.z) / W.d.z;
 }
 
-__device__ __forceinline__ void walk_pop(KdWalk& W, const uint32_t* stack_i, const float* stack_t)
+constexpr uint32_t kWalkSweep = 8u; // KdWalk::neg bit: stackless sweep
+
+// Next node for a lane that has finished one: continues a stackless sweep if one is under way (stops at the
+// next leaf whose boxes pass: the caller tests its triangles and comes back), else pops the short stack.
+template <typename Stack>
+__device__ __forceinline__ void walk_pop(KdWalk& W, const Stack& st)
 {
     W.cur = kWalkNone;
+    if (W.neg & kWalkSweep) {
+        uint32_t i = W.cr;
+        const uint32_t end = __float_as_uint(W.cs);
+        while (i < end) {
+            const float4* __restrict__ q = reinterpret_cast<const float4*>(W.kd + i);
+            const float4 h = q[0], x = q[1], y = q[2], z = q[3];
+            const uint32_t a = __float_as_uint(h.x), b = __float_as_uint(h.y);
+            const float t1 = (x.x - W.o.x) / W.d.x, t2 = (x.w - W.o.x) / W.d.x;
+            const float t3 = (x.y - W.o.y) / W.d.y, t4 = (y.x - W.o.y) / W.d.y;
+            const float t5 = (x.z - W.o.z) / W.d.z, t6 = (y.y - W.o.z) / W.d.z;
+            float bound;
+            const bool pass = slab_decide(t1, t2, t3, t4, t5, t6) && !kd_prune(y, z, W.o, W.inv, W.oabs, W.best_d, bound);
+            const bool leaf = (b & kKdCountMask) != 0u;
+            if (pass && leaf) {
+                W.cur = i;
+                W.ca = a;
+                W.cb = b;
+                W.cr = i + 1u;
+                return;
+            }
+            i = (pass || leaf) ? i + 1u : a; // an interior node that fails takes its skip link
+        }
+        W.neg &= ~kWalkSweep;
+    }
     while (W.sp > 0) {
         --W.sp;
-        if (stack_t[W.sp] > W.best_d) continue;
-        walk_enter(W, stack_i[W.sp]);
+        if (st.dist(W.sp) > W.best_d) continue;
+        walk_enter(W, st.node(W.sp));
         break;
     }
 }
@@ -481,8 +535,8 @@ __device__ __forceinline__ void walk_begin(KdWalk& W, const DScene& S, const DMe
 // lane whose two children both fail does not pop at once (a pop re-enters a node: six IEEE divides, for
 // the one or two lanes that need it) but parks itself as kWalkPop; the walker kernel pops such lanes
 // together.
-template <bool DEFER_POP>
-__device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] const DScene& S, uint32_t* stack_i, float* stack_t)
+template <bool DEFER_POP, typename Stack>
+__device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] const DScene& S, const Stack& st, int cap)
 {
     PTK_STAT_ACTIVE(S, 16);
     const DKdNode* __restrict__ kd = W.kd;
@@ -509,9 +563,17 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
     const bool er = has_r && slab_decide(R1, T2, R3, T4, R5, T6) && !kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
     const bool right_first = ((W.neg >> k) & 1u) != 0u;
     const bool take_r = er && (right_first || !el);
-    if (el && er && W.sp < kKdStack) {
-        stack_i[W.sp] = take_r ? li : ri;
-        stack_t[W.sp] = take_r ? bl : br;
+    if (el && er && W.sp >= cap) {
+        // short stack full: no ordering below this node, sweep its subtree [cur + 1, ca) instead (see kWalkStack)
+        W.neg |= kWalkSweep;
+        W.cr = li;
+        W.cs = __uint_as_float(ca);
+        if (DEFER_POP) W.cur = kWalkPop;
+        else walk_pop(W, st);
+        return;
+    }
+    if (el && er) {
+        st.put(W.sp, take_r ? li : ri, take_r ? bl : br);
         ++W.sp;
     }
     if (el || er) {
@@ -526,18 +588,18 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
     } else if (DEFER_POP) {
         W.cur = kWalkPop;
     } else {
-        walk_pop(W, stack_i, stack_t);
+        walk_pop(W, st);
     }
 }
 
 // One round of the closed per-lane loop: descend until the lane stands on a leaf (or has run out of
 // nodes), then test that leaf and pop.
-__device__ __forceinline__ void walk_round(KdWalk& W, const DScene& S, uint32_t* stack_i, float* stack_t)
+__device__ __forceinline__ void walk_round(KdWalk& W, const DScene& S, const LocalStack& st, int cap)
 {
-    while (W.cur != kWalkNone && (W.cb & kKdCountMask) == 0u) walk_descend_step<false>(W, S, stack_i, stack_t);
+    while (W.cur != kWalkNone && (W.cb & kKdCountMask) == 0u) walk_descend_step<false>(W, S, st, cap);
     if (W.cur != kWalkNone) {
         leaf_triangles(S, W.leaf_base + W.ca, W.cb & kKdCountMask, W.o, W.d, W.best_d, W.best_slot, W.found, W.bar, W.p);
-        walk_pop(W, stack_i, stack_t);
+        walk_pop(W, st);
     }
 }
 
@@ -546,6 +608,8 @@ __device__ __forceinline__ void kd_walk_pruned(const DScene& S, const DMesh mesh
 {
     uint32_t stack_i[kKdStack];
     float stack_t[kKdStack];
+    const LocalStack st{ stack_i, stack_t };
+    const int cap = (int)S.walk_stack < kKdStack ? (int)S.walk_stack : kKdStack;
     KdWalk W;
     walk_begin(W, S, mesh, o, d, work);
     // results so far (a one-leaf root the caller already tested) carry over
@@ -554,7 +618,7 @@ __device__ __forceinline__ void kd_walk_pruned(const DScene& S, const DMesh mesh
     W.found = found;
     W.bar = bar_out;
     W.p = p_out;
-    while (W.cur != kWalkNone) walk_round(W, S, stack_i, stack_t);
+    while (W.cur != kWalkNone) walk_round(W, S, st, cap);
     best_d = W.best_d;
     best_slot = W.best_slot;
     found = W.found;
@@ -1376,6 +1440,8 @@ struct alignas(16) WalkLds {
     unsigned long long start_mask[64]; // per 64-item chunk: bit i set = an owner's items start at item 64 * chunk + i
     float pay[6][64];                  // bar, p of the lane's best triangle this stage
     uint8_t owner[64];                 // k-th waiting lane
+    uint32_t stack_i[kWalkStack][64];  // short stack of the lanes' pending far children (LdsStack) ...
+    float stack_t[kWalkStack][64];     // ... and their distance bounds
 };
 
 __device__ __forceinline__ uint32_t lane_get_u32(uint32_t v, uint32_t src)

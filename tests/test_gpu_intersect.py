@@ -127,6 +127,40 @@ def test_single_child_kd_nodes(gpu_ctx):
     assert (r["prim"] >= 0).sum() > 10_000
 
 
+@pytest.mark.parametrize("limit", [0, 1, 3])
+def test_short_stack_overflow_sweeps_the_subtree(gpu_ctx, limit):
+    """The pruned KD walk keeps a short stack of pending far children (12 entries per lane in LDS in the walker, 16 in
+    the per-lane loops).  When it is full the walk sweeps the current subtree in preorder through the skip links
+    instead of spilling.  PTK_OPT_WALK_STACK forces that path: with a limit of 0, 1 or 3 entries nearly every ray
+    sweeps, with subtrees nested inside swept subtrees, and the hits must still be the oracle's, id for id."""
+    from oracle import oracle
+    from pathtracing_amd import _abi, scene as S
+    sc = S.Scene()
+    for k, (n, seed) in enumerate([(12000, 61), (3000, 62)]):
+        node = S.SceneNode()
+        node.translate([1.2 * k, 0.1 * k, -0.4 * k])
+        node.rotate([0.3, 1.0, 0.2], 0.5 + k)
+        node.shape = S.Mesh(random_soup(n, seed, extent=1.0, size=0.1))
+        sc.nodes.append(node)
+    two = random_soup(2, 14)            # two triangles no split separates: a chain down to depth 100
+    two[1, :, 0:3] = two[0, :, 0:3] * np.float32(1.5)
+    chain = S.SceneNode()
+    chain.translate([-1.5, 0.0, 0.0])
+    chain.shape = S.Mesh(two)
+    sc.nodes.append(chain)
+    ora = oracle.OracleScene(sc)
+    o, d = random_rays(150_000, 77, -2.5, 2.5)
+    ref = ora.intersect_batch(o, d)
+    try:
+        gpu_ctx.set_option(_abi.PTK_OPT_WALK_STACK, limit)
+        gpu_ctx.upload(sc)
+        got = gpu_ctx.intersect_batch(o, d)
+    finally:
+        gpu_ctx.set_option(_abi.PTK_OPT_WALK_STACK, 64)
+    check_batch(got, ref)
+    assert (ref["prim"] >= 0).sum() > 10_000 and (ref["node"] == 2).sum() > 0
+
+
 def test_ragged_and_empty_batches(gpu_ctx):
     ora = get_oracle("room")
     gpu_ctx.upload(get_scene("room"))

@@ -145,14 +145,14 @@ __device__ __forceinline__ void shade_hit(const DScene& S, const Hit& h, V3 d, f
     const float metallic = sampler_sample(S, s_metallic, uvx, uvy).x;
     // pathtracer.cpp:40-54
     const V3 hemi = hemisphere_dir(n, u1, u2);
-    const V3 refl = d - n * dot(n, d) * 2.0f;
-    const V3 dir = normalize(mix(refl, hemi, roughness));
-    const float dn = dot(dir, n);
+    const V3 refl = sh_madd(n, -2.0f * sh_dot(n, d), d);
+    const V3 dir = sh_normalize(sh_mix(refl, hemi, roughness));
+    const float dn = sh_dot(dir, n);
     const float cos_theta = (0.0f < dn) ? dn : 0.0f;
     // pathtracer.cpp:60
-    const V3 m = mix(albedo, mk(1.0f, 1.0f, 1.0f), metallic);
-    weight = m * cos_theta * 2.0f;
-    o_next = h.pw + dir * PTK_EPSILON;
+    const V3 m = sh_mix(albedo, mk(1.0f, 1.0f, 1.0f), metallic);
+    weight = m * (cos_theta * 2.0f);
+    o_next = sh_madd(dir, PTK_EPSILON, h.pw);
     d_next = dir;
 }
 
@@ -178,7 +178,7 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
         const V3 emission = sampler_sample(S, s_emission, uvx, uvy);
         const float roughness = sampler_sample(S, s_roughness, uvx, uvy).x;
         const float metallic = sampler_sample(S, s_metallic, uvx, uvy).x;
-        L = L + mulv(T, emission);
+        L = mk(__builtin_fmaf(T.x, emission.x, L.x), __builtin_fmaf(T.y, emission.y, L.y), __builtin_fmaf(T.z, emission.z, L.z));
         if (A.bounce + 1 < PTK_MAX_DEPTH) {
             const uint32_t pl = path / A.samples;
             const uint32_t sm = path - pl * A.samples;
@@ -186,14 +186,14 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
             rng_pair(A.seed, (uint32_t)(A.pixel_begin + pl), A.sample_begin + sm, 1u + A.bounce, u1, u2);
             // pathtracer.cpp:40-54
             const V3 hemi = hemisphere_dir(n, u1, u2);
-            const V3 refl = d - n * dot(n, d) * 2.0f;
-            const V3 dir = normalize(mix(refl, hemi, roughness));
-            const float dn = dot(dir, n);
+            const V3 refl = sh_madd(n, -2.0f * sh_dot(n, d), d);
+            const V3 dir = sh_normalize(sh_mix(refl, hemi, roughness));
+            const float dn = sh_dot(dir, n);
             const float cos_theta = (0.0f < dn) ? dn : 0.0f;
             // pathtracer.cpp:60 in throughput form
-            const V3 m = mix(albedo, mk(1.0f, 1.0f, 1.0f), metallic);
-            T = mulv(T, m) * cos_theta * 2.0f;
-            o = h.pw + dir * PTK_EPSILON;
+            const V3 m = sh_mix(albedo, mk(1.0f, 1.0f, 1.0f), metallic);
+            T = mulv(T, m) * (cos_theta * 2.0f);
+            o = sh_madd(dir, PTK_EPSILON, h.pw);
             d = dir;
             alive = (T.x != 0.0f) || (T.y != 0.0f) || (T.z != 0.0f);
         }

@@ -188,6 +188,30 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b)
 __device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
 __device__ __forceinline__ V3 mix(V3 x, V3 y, float a) { return x * (1.0f - a) + y * a; }
 
+// ---- shading arithmetic --------------------------------------------------------------------------------
+// Everything above replays the reference's rounding because it feeds hit DECISIONS.  What follows a decided hit
+// (normal, bounce direction, weights: pathtracer.cpp:34-60, rng.cpp:12-36) is held to a tolerance instead
+// (tests/test_gpu_probes.py: 2e-5 on unit vectors and weights against the oracle), so it may use fused
+// multiply-adds and the hardware's 1-ulp reciprocal square root / square root: about a quarter of the
+// shading stage's instructions.
+__device__ __forceinline__ float sh_dot(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ V3 sh_normalize(V3 a) { return a * __builtin_amdgcn_rsqf(sh_dot(a, a)); }
+__device__ __forceinline__ V3 sh_madd(V3 a, float s, V3 c) // a * s + c
+{
+    return mk(__builtin_fmaf(a.x, s, c.x), __builtin_fmaf(a.y, s, c.y), __builtin_fmaf(a.z, s, c.z));
+}
+__device__ __forceinline__ V3 sh_mix(V3 x, V3 y, float a) { return sh_madd(y, a, x * (1.0f - a)); }
+__device__ __forceinline__ V3 sh_cross(V3 a, V3 b)
+{
+    return mk(__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y)));
+}
+// mat4 * vec4(p, 0) -> xyz
+__device__ __forceinline__ V3 sh_mat_dir(const float* __restrict__ m, V3 p)
+{
+    return mk(__builtin_fmaf(m[0], p.x, __builtin_fmaf(m[4], p.y, m[8] * p.z)), __builtin_fmaf(m[1], p.x, __builtin_fmaf(m[5], p.y, m[9] * p.z)),
+              __builtin_fmaf(m[2], p.x, __builtin_fmaf(m[6], p.y, m[10] * p.z)));
+}
+
 // sin and cos of 2 pi u for the hemisphere sample (rng.cpp:29-31), shading only: one argument
 // reduction and two polynomials (error < 1e-7 on [0, 2 pi)) instead of the library's full-range
 // sinf and cosf, which differ from the host libm's in the last place just the same.  (The 1-ulp
@@ -1560,7 +1584,7 @@ __device__ __forceinline__ void hit_attributes(const DScene& S, const Hit& h, V3
         u_out = h.a1;
         v_out = h.a2;
     }
-    nl = normalize(nl);
+    nl = ALWAYS_UV ? normalize(nl) : sh_normalize(nl); // the parity entry reports the reference's rounding
     if (h.prim < 0) {
         // sphere: scene.cpp:434-437
         if (ALWAYS_UV || nd->uses_uv != 0u) uvx = atan2f(nl.x, nl.z) / 3.14159265358979323846f + 0.5f;
@@ -1568,7 +1592,7 @@ __device__ __forceinline__ void hit_attributes(const DScene& S, const Hit& h, V3
         u_out = uvx;
         v_out = uvy;
     }
-    n_world = normalize(mat_point(nd->nrm, nl, 0.0f));
+    n_world = ALWAYS_UV ? normalize(mat_point(nd->nrm, nl, 0.0f)) : sh_normalize(sh_mat_dir(nd->nrm, nl));
 }
 
 // ---------------------------------------------------------------- samplers
@@ -1666,20 +1690,20 @@ __device__ __forceinline__ void rng_pair(uint64_t seed, uint32_t pixel, uint64_t
     u2 = u01((j & 1u) ? r.w : r.y);
 }
 
-// rng::hemisphere, rng.cpp:12-36
+// rng::hemisphere, rng.cpp:12-36 (shading arithmetic)
 __device__ __forceinline__ V3 hemisphere_dir(V3 n, float u1, float u2)
 {
     // rng.cpp:16-21: one of two tangents; the operands are selected first so that a wave whose
     // lanes disagree runs the normalisation once (same operations on the same values either way)
     const bool xc = fabsf(n.x) > fabsf(n.y);
-    const V3 t = normalize(mk(xc ? n.z : 0.0f, xc ? 0.0f : -n.z, xc ? -n.x : n.y));
-    const V3 b = cross(n, t);
+    const V3 t = sh_normalize(mk(xc ? n.z : 0.0f, xc ? 0.0f : -n.z, xc ? -n.x : n.y));
+    const V3 b = sh_cross(n, t);
     const float z = u1;
-    const float r = sqrtf(1.0f - z * z);
+    const float r = __builtin_amdgcn_sqrtf(__builtin_fmaf(-z, z, 1.0f));
     float sn, cs;
     sincos_2pi_shade(u2, sn, cs);
     const float tx = r * cs, ty = r * sn;
-    return t * tx + b * ty + n * z;
+    return sh_madd(t, tx, sh_madd(b, ty, n * z));
 }
 
 // abstract_pathtracer.cpp:74-83

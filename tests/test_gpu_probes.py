@@ -102,7 +102,7 @@ def test_equirect_background(probe_ctx):
 def test_hemisphere_mapping(probe_ctx):
     """rng::hemisphere (rng.cpp:12-36): both tangent branches (|n.x| > |n.y| and not, including the tie), the draws'
     corners (z = 0, z -> 1, phi = 0 and -> 2 pi).  The device evaluates sin / cos of 2 pi u with its own reduced-range
-    polynomials: 3e-7 absolute on unit vectors."""
+    polynomials, fused multiply-adds and the 1-ulp hardware rsq / sqrt: 1e-6 absolute on unit vectors."""
     from oracle import oracle
     probe_ctx.upload(get_scene("furnace"))
     rng = np.random.default_rng(5)
@@ -117,7 +117,7 @@ def test_hemisphere_mapping(probe_ctx):
     u[: len(corners)] = corners
     got = probe_ctx.probe_hemisphere(n, u)
     ref = oracle.hemisphere(n, u)
-    assert np.abs(got - ref).max() <= 3e-7, np.abs(got - ref).max()
+    assert np.abs(got - ref).max() <= 1e-6, np.abs(got - ref).max()
     # the mapping's own properties: unit length, z = u1 along the normal
     assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() < 1e-5
     assert np.abs((got * n).sum(axis=1) - u[:, 0]).max() < 1e-5

@@ -264,6 +264,18 @@ int ptk_render_samples_noalloc_dev(ptk_ctx* ctx, uint64_t seed,
                                    uint64_t sample_begin, uint32_t sample_count,
                                    float* sum_rgb_dev, int accumulate);
 
+/* Debug AOVs: rt::utility::debug_pathtracer::trace
+ * (PathtracingUtility/debug_pathtracer.cpp:8-32, modes of debug_pathtracer.h:16-23) in place of
+ * pathtracer::trace for the same pixel / sample ranges as ptk_render_samples_dev: the jittered primary
+ * ray is cast, a hit yields the node's albedo / emission / roughness / metallic sampler at the hit's
+ * uv (all three channels) or normal * 0.5 + 0.5, a miss the background.  Sums go to sum_rgb_dev like
+ * ptk_render_samples_dev's; ptk_resolve_iteration_dev applies the running mean. */
+enum { PTK_AOV_ALBEDO = 0, PTK_AOV_EMISSION = 1, PTK_AOV_ROUGHNESS = 2, PTK_AOV_METALLIC = 3, PTK_AOV_NORMAL = 4 };
+int ptk_render_aov_dev(ptk_ctx* ctx, uint32_t aov, uint64_t seed,
+                       uint64_t pixel_begin, uint64_t pixel_count,
+                       uint64_t sample_begin, uint32_t sample_count,
+                       float* sum_rgb_dev, int accumulate);
+
 /* abstract_pathtracer.cpp:66,88-90: image = mix(sum/spi, image, it/float(it+1)). */
 int ptk_resolve_iteration_dev(ptk_ctx* ctx, const float* sum_rgb_dev, float* image_rgb_dev,
                               uint64_t samples_per_iteration, uint64_t iteration);
@@ -412,6 +424,9 @@ int ptk_group_render_begin(ptk_group* group, uint32_t width, uint32_t height, fl
  * member 0 and folded into its running-mean image.  Synchronises. */
 int ptk_group_render_iteration(ptk_group* group, uint64_t seed, uint64_t iteration,
                                uint64_t samples_per_iteration);
+/* The same with ptk_render_aov_dev in place of ptk_render_samples_dev (aov = PTK_AOV_*). */
+int ptk_group_render_aov_iteration(ptk_group* group, uint32_t aov, uint64_t seed, uint64_t iteration,
+                                   uint64_t samples_per_iteration);
 /* Member 0's running-mean image -> host (width*height*3 floats, row 0 = top). */
 int ptk_group_read_image(ptk_group* group, float* image_rgb);
 /* Sum of the members' counters. */

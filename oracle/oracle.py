@@ -51,6 +51,7 @@ def load():
         lib.orc_secondary_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_set_walk_model.argtypes = [C.c_int]
+        lib.orc_render_aov.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
         lib.orc_tonemap.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         lib.orc_shade_probe.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 8
         _lib = lib
@@ -181,6 +182,16 @@ def _shade_probe(self, origins, directions, u12):
 
 
 OracleScene.shade_probe = _shade_probe
+
+
+def _render_aov(self, aov, w, h, fov_y, seed, spp):
+    """Mean of debug_pathtracer::trace over spp jittered primary rays per pixel -> (h, w, 3)."""
+    out = np.zeros((h, w, 3), np.float32)
+    self._lib.orc_render_aov(self._h, aov, w, h, float(np.float32(fov_y)), seed, 0, spp, out.ctypes.data)
+    return out / np.float32(spp)
+
+
+OracleScene.render_aov = _render_aov
 
 
 def tonemap(image_rgb):

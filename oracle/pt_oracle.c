@@ -1111,6 +1111,38 @@ void orc_tonemap(const float* rgb, uint64_t n, uint32_t* rgba, float* scaled)
     }
 }
 
+/* rt::utility::debug_pathtracer::trace (PathtracingUtility/debug_pathtracer.cpp:8-32) summed over the jittered primary
+ * rays of a sample range, like orc_render_samples (single thread).  aov: 0 albedo, 1 emission, 2 roughness,
+ * 3 metallic, 4 normal (debug_pathtracer.h:16-23). */
+void orc_render_aov(const orc_scene* s, uint32_t aov, uint32_t w, uint32_t h, float fov_y, uint64_t seed,
+                    uint64_t sample_begin, uint32_t sample_count, float* sum_rgb)
+{
+    const view_t view = make_view(s, w, h, fov_y);
+    rng_t g;
+    g.mode = 0;
+    for (uint64_t p = 0; p < (uint64_t)w * h; ++p) {
+        v3 color = V3(0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 0; k < sample_count; ++k) {
+            rng_begin_path(&g, seed, (uint32_t)p, sample_begin + k);
+            const float u1 = rng_next(&g);
+            const float u2 = rng_next(&g);
+            const ray_t r = primary_ray(s, &view, w, h, (uint32_t)(p % w), (uint32_t)(p / w), u1, u2);
+            int32_t node;
+            const hit_t res = scene_cast_ray(s, &r, &node, NULL, NULL);
+            v3 c;
+            if (res.hit) {
+                const ptk_node_desc* nd = &s->nodes[node];
+                if (aov == 4) c = add3(scale3(res.normal, 0.5f), V3(0.5f, 0.5f, 0.5f));
+                else c = sampler_sample(s, aov == 0 ? nd->albedo : aov == 1 ? nd->emission : aov == 2 ? nd->roughness : nd->metallic, res.uv);
+            } else {
+                c = background_sample(s, r.d);
+            }
+            color = add3(color, c);
+        }
+        sum_rgb[p * 3] = color.x; sum_rgb[p * 3 + 1] = color.y; sum_rgb[p * 3 + 2] = color.z;
+    }
+}
+
 void orc_primary_rays(const orc_scene* s, uint32_t w, uint32_t h, float fov_y, uint64_t n, const uint32_t* xy,
                       const float* u12, float* o, float* d)
 {

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("PTK_LIB") or os.path.join(_HERE, "libptk.so")
 PTK_OK = 0
 PTK_ERR_INVALID, PTK_ERR_HIP, PTK_ERR_STATE, PTK_ERR_NOMEM = 1, 2, 3, 4
 PTK_MAX_DEPTH = 5
+PTK_AOV_ALBEDO, PTK_AOV_EMISSION, PTK_AOV_ROUGHNESS, PTK_AOV_METALLIC, PTK_AOV_NORMAL = range(5)
 PTK_NOALLOC_MAX_PATHS = 1 << 18
 PTK_SAMPLER_COLOR, PTK_SAMPLER_IMAGE = 0, 1
 PTK_MODE_LINEAR, PTK_MODE_NEAREST = 0, 1
@@ -138,6 +139,7 @@ SYMBOLS = {
     "ptk_render_begin": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64]),
     "ptk_render_samples_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int]),
     "ptk_render_samples_noalloc_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int]),
+    "ptk_render_aov_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int]),
     "ptk_resolve_iteration_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "ptk_render_image": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "ptk_tonemap_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -164,6 +166,7 @@ SYMBOLS = {
     "ptk_group_scene_set_camera": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc)]),
     "ptk_group_render_begin": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64]),
     "ptk_group_render_iteration": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "ptk_group_render_aov_iteration": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]),
     "ptk_group_read_image": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ptk_group_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "ptk_scene_kd_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(KdInfo)]),

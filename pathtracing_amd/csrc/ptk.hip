@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -270,6 +271,15 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V
         Hit h;
         intersect_scene_mode<MODE, FIRST>(S, o, d, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
 
+#ifdef PTK_EXP
+        if (S.exp_stage != 0u) { // no shading: the hit goes out through the radiance slots so that the cast is not dead code
+            if (on) {
+                A.sample_L[0 * A.cap + path] = h.d0;
+                A.sample_L[1 * A.cap + path] = __int_as_float(h.node);
+                A.sample_L[2 * A.cap + path] = h.a0 + h.a1 + h.a2 + h.pw.x + h.pw.y + h.pw.z + __int_as_float(h.prim);
+            }
+        } else
+#endif
         if (on) alive = shade_ray(S, A, h, o, d, T, L, path);
     }
 
@@ -887,6 +897,38 @@ __global__ __launch_bounds__(kBlock) void k_probe_shade(const DScene S, const Sh
     if (P.next_d) { P.next_d[i] = nd.x; P.next_d[n + i] = nd.y; P.next_d[2 * n + i] = nd.z; }
 }
 
+// ---- debug AOVs: rt::utility::debug_pathtracer::trace (debug_pathtracer.cpp:8-32) for the jittered
+// primary ray of every (pixel, sample) of a chunk: cast, then the chosen material channel at the hit, the shading
+// normal mapped to [0, 1], or the background on a miss.  Same ray generation, cast and sample_L / k_accumulate path
+// as bounce 0 of the integrator.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_aov(const DScene S, const DView V, const BounceArgs A, const uint32_t aov)
+{
+    __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const bool on = slot < A.n_paths;
+    const uint32_t path = on ? slot : 0u;
+    V3 o, d;
+    primary_ray(S, V, A, path, o, d);
+    Hit h;
+    intersect_scene_mode<MODE, true>(S, o, d, on, h, &wave_lds[(MODE & 8) ? threadIdx.x >> 6 : 0]);
+    if (!on) return;
+    V3 c;
+    if (h.node < 0) {
+        c = background_sample(S, d); // debug_pathtracer.cpp:29
+    } else {
+        V3 n;
+        float uvx, uvy, uu, vv;
+        int prim_id;
+        hit_attributes<true>(S, h, n, uvx, uvy, prim_id, uu, vv);
+        if (aov == PTK_AOV_NORMAL) c = n * 0.5f + mk(0.5f, 0.5f, 0.5f); // debug_pathtracer.cpp:25
+        else c = sampler_sample(S, S.node_samplers[(size_t)h.node * 4 + (aov == PTK_AOV_ALBEDO ? 0u : aov == PTK_AOV_EMISSION ? 1u : aov == PTK_AOV_ROUGHNESS ? 2u : 3u)], uvx, uvy);
+    }
+    A.sample_L[0 * A.cap + path] = c.x;
+    A.sample_L[1 * A.cap + path] = c.y;
+    A.sample_L[2 * A.cap + path] = c.z;
+}
+
 std::string g_create_error;
 
 } // namespace
@@ -924,6 +966,7 @@ struct ptk_ctx {
     int split = 2;     // PTK_OPT_SPLIT
     int device_kd = 2; // PTK_OPT_DEVICE_KD
     int walk_stack = 64; // PTK_OPT_WALK_STACK (clamped to the kernels' own capacity)
+    int exp_stage = 0;   // PTK_EXP builds: stage limit of bounce 2 (environment PTK_EXP_STAGE)
     uint32_t num_trees = 0; // nodes of class kClassTree
 
     // split mode (scenes with KD-trees): second ray queue, parked-ray list, counters
@@ -1513,7 +1556,12 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
                 PTK_HIP(c, hipGetLastError());
                 continue;
             }
+#ifdef PTK_EXP
+            DScene Sx = c->S; // stage limit on bounce 2 only: its input rays are those of a normal run
+#define PTK_BOUNCE(F, M) (Sx.exp_stage = (A.bounce == 2u) ? (uint32_t)c->exp_stage : 0u, k_bounce<F, M><<<grid, block, 0, c->stream>>>(Sx, c->V, A))
+#else
 #define PTK_BOUNCE(F, M) k_bounce<F, M><<<grid, block, 0, c->stream>>>(c->S, c->V, A)
+#endif
             {
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
                 switch (kernel_mode(c, true)) {
@@ -1582,6 +1630,7 @@ int ptk_ctx_create(int device, ptk_ctx** out)
         return PTK_ERR_HIP;
     }
     c->stream = c->own_stream;
+    if (const char* e = std::getenv("PTK_EXP_STAGE")) c->exp_stage = std::atoi(e);
     noalloc_scratch_init(device); // `device` is current here
     *out = c;
     return PTK_OK;
@@ -2236,6 +2285,60 @@ int ptk_render_samples_noalloc_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_beg
     const int rc = render_samples_impl(c, R, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb, accumulate);
     c->timing_hold = false;
     return rc;
+}
+
+int ptk_render_aov_dev(ptk_ctx* c, uint32_t aov, uint64_t seed, uint64_t pixel_begin, uint64_t pixel_count, uint64_t sample_begin,
+                       uint32_t sample_count, float* sum_rgb, int accumulate)
+{
+    if (!c) return PTK_ERR_INVALID;
+    if (!c->has_scene || !c->has_view) return fail(c, PTK_ERR_STATE, "ptk_render_aov: call ptk_render_begin first");
+    if (aov > PTK_AOV_NORMAL) return fail(c, PTK_ERR_INVALID, "ptk_render_aov: unknown AOV");
+    if (!sum_rgb) return fail(c, PTK_ERR_INVALID, "ptk_render_aov: NULL sum buffer");
+    const uint64_t num_pixels = (uint64_t)c->V.width * c->V.height;
+    if (pixel_begin > num_pixels || pixel_count > num_pixels - pixel_begin)
+        return fail(c, PTK_ERR_INVALID, "ptk_render_aov: pixel range outside the viewport");
+    if (pixel_count == 0) return PTK_OK;
+    if (int r = set_device(c)) return r;
+    if (sample_count == 0) {
+        if (!accumulate) PTK_HIP(c, hipMemsetAsync(sum_rgb + pixel_begin * 3, 0, pixel_count * 3 * sizeof(float), c->stream));
+        return PTK_OK;
+    }
+    const uint64_t cap = c->cap;
+    const uint32_t s_chunk = (uint32_t)((uint64_t)sample_count < cap ? sample_count : cap);
+    const uint64_t p_chunk = cap / s_chunk;
+    for (uint32_t s0 = 0; s0 < sample_count; s0 += s_chunk) {
+        const uint32_t ns = (sample_count - s0 < s_chunk) ? sample_count - s0 : s_chunk;
+        const int acc = (accumulate || s0 > 0) ? 1 : 0;
+        for (uint64_t p0 = 0; p0 < pixel_count; p0 += p_chunk) {
+            const uint64_t np = (pixel_count - p0 < p_chunk) ? pixel_count - p0 : p_chunk;
+            BounceArgs A{};
+            A.sample_L = c->d_sample_L;
+            A.cap = cap;
+            A.n_paths = (uint32_t)(np * ns);
+            A.num_segments = (A.n_paths + kBlock - 1) / kBlock;
+            A.samples = ns;
+            A.pixel_begin = pixel_begin + p0;
+            A.sample_begin = sample_begin + s0;
+            A.seed = seed;
+            const dim3 grid(A.num_segments), block(kBlock);
+#define PTK_AOV(M) k_aov<M><<<grid, block, 0, c->stream>>>(c->S, c->V, A, aov)
+            switch (kernel_mode(c, true)) {
+            case 0: PTK_AOV(0); break;
+            case 1: PTK_AOV(1); break;
+            case 2: PTK_AOV(2); break;
+            case 3: PTK_AOV(3); break;
+            case 5: PTK_AOV(5); break;
+            case 7: PTK_AOV(7); break;
+            case 8: PTK_AOV(8); break;
+            default: PTK_AOV(10); break;
+            }
+#undef PTK_AOV
+            hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((np * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->d_sample_L, cap,
+                               (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
+            PTK_HIP(c, hipGetLastError());
+        }
+    }
+    return PTK_OK;
 }
 
 int ptk_resolve_iteration_dev(ptk_ctx* c, const float* sum_rgb, float* image_rgb, uint64_t spi, uint64_t iteration)

@@ -137,6 +137,12 @@ struct DScene {
 #ifdef PTK_STATS
     unsigned long long* stats; // experiment builds only: work counters of the balanced traversal
 #endif
+#ifdef PTK_EXP
+    // experiment builds only (scripts/stage_budget.sh): the launch stops after a stage of the bounce kernel, so that
+    // per-dispatch instruction counters of successive builds give a per-stage budget.  0 = whole kernel, 1 = load +
+    // cull loop only, 2 = + ray -> local / sphere / box stage, 3 = + triangle stage (whole cast), no shading.
+    uint32_t exp_stage;
+#endif
 };
 #ifdef PTK_STATS
 #define PTK_STAT(S, k, v) do { if (lane_id() == 0u && (blockIdx.x & 15u) == 0u) atomicAdd((S).stats + (k), (unsigned long long)(v)); } while (0) // every 16th block: same-line atomics are slow enough to distort the clocks
@@ -1425,9 +1431,17 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             advance();
         }
         const uint32_t qn = qtail - qhead;
+#ifdef PTK_EXP
+        if (S.exp_stage == 1u) qhead = qtail;
+        else
+#endif
         if (qn != 0u) process(qn < 64u ? qn : 64u);
         const bool drained = n >= S.num_nodes && qtail == qhead;
         const uint32_t sn = stail - shead;
+#ifdef PTK_EXP
+        if (S.exp_stage == 1u || S.exp_stage == 2u) shead = stail;
+        else
+#endif
         if (sn >= 64u || (drained && sn != 0u)) flush(sn < 64u ? sn : 64u);
         if (drained && stail == shead) break;
     }

@@ -242,7 +242,21 @@ int ptk_group_render_begin(ptk_group* g, uint32_t width, uint32_t height, float 
     return PTK_OK;
 }
 
+static int group_iteration(ptk_group* g, int aov, uint64_t seed, uint64_t iteration, uint64_t samples_per_iteration);
+
 int ptk_group_render_iteration(ptk_group* g, uint64_t seed, uint64_t iteration, uint64_t samples_per_iteration)
+{
+    return group_iteration(g, -1, seed, iteration, samples_per_iteration);
+}
+
+int ptk_group_render_aov_iteration(ptk_group* g, uint32_t aov, uint64_t seed, uint64_t iteration, uint64_t samples_per_iteration)
+{
+    if (aov > PTK_AOV_NORMAL) return gfail(g, PTK_ERR_INVALID, "ptk_group_render_aov_iteration: unknown AOV");
+    return group_iteration(g, (int)aov, seed, iteration, samples_per_iteration);
+}
+
+// aov < 0: the integrator (ptk_render_samples_dev); otherwise ptk_render_aov_dev
+static int group_iteration(ptk_group* g, int aov, uint64_t seed, uint64_t iteration, uint64_t samples_per_iteration)
 {
     if (!g) return PTK_ERR_INVALID;
     if (!g->image) return gfail(g, PTK_ERR_STATE, "ptk_group_render_iteration: call ptk_group_render_begin first");
@@ -259,8 +273,9 @@ int ptk_group_render_iteration(ptk_group* g, uint64_t seed, uint64_t iteration, 
         else split_range(num_pixels, m, n, p0, np);
         if (n > 1 && (np != num_pixels || ns == 0)) // pixels outside the share contribute 0 to the reduce
             if (int rc = from_ctx(g, (int)m, ptk_dev_memset(g->ctx[m], g->sum[m], 0, floats * sizeof(float)))) return rc;
-        if (int rc = from_ctx(g, (int)m, ptk_render_samples_dev(g->ctx[m], seed, p0, np, iteration * spi + s0, (uint32_t)ns, g->sum[m], 0)))
-            return rc;
+        const int rc = aov < 0 ? ptk_render_samples_dev(g->ctx[m], seed, p0, np, iteration * spi + s0, (uint32_t)ns, g->sum[m], 0)
+                               : ptk_render_aov_dev(g->ctx[m], (uint32_t)aov, seed, p0, np, iteration * spi + s0, (uint32_t)ns, g->sum[m], 0);
+        if (from_ctx(g, (int)m, rc)) return rc;
     }
     for (uint64_t m = 0; m < n; ++m)
         if (int rc = from_ctx(g, (int)m, ptk_ctx_synchronize(g->ctx[m]))) return rc;

@@ -26,6 +26,16 @@ public:
     enum class mode { albedo, emission, roughness, metallic, normal };
     mode current_mode = mode::albedo;
     glm::vec3 trace(const view_parameters& params, const ray& ray, const scene& scene) override;
+
+    // Additive: run() renders this tracer's AOVs on the GPU (ptk_render_aov_dev) when use_device is set (default);
+    // cleared, it is driven on host threads through trace() like any other subclass, as in the reference.
+    bool use_device = true;
+    int device = 0;
+    uint64_t seed = 0;
+
+private:
+    friend class rt::abstract_pathtracer;
+    std::shared_ptr<detail::device_session> m_session;
 };
 
 } // namespace utility

@@ -276,7 +276,7 @@ std::shared_ptr<device_session> make_device_session() { return std::make_shared<
 
 std::shared_ptr<pathtracer_result> run_on_device(const view_parameters& view, const trace_parameters& params, scene& sc,
                                                  const std::vector<int>& devices, uint64_t seed, uint64_t max_paths,
-                                                 std::shared_ptr<device_session> session, device_run_info* info)
+                                                 std::shared_ptr<device_session> session, device_run_info* info, int aov)
 {
     using clock = std::chrono::steady_clock;
     const auto t0 = clock::now();
@@ -328,7 +328,7 @@ std::shared_ptr<pathtracer_result> run_on_device(const view_parameters& view, co
     if (info) info->prepare_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
 
     // `held` travels with the driver thread's closure: the session is free again when the run is over
-    return std::make_shared<pathtracer_result>([session, held, group, view, params, seed, max_paths](pathtracer_result& self) mutable {
+    return std::make_shared<pathtracer_result>([session, held, group, view, params, seed, max_paths, aov](pathtracer_result& self) mutable {
         image frame(view.width, view.height);
         const uint64_t num_pixels = uint64_t(view.width) * view.height;
         auto ok = [&](int rc) {
@@ -344,7 +344,9 @@ std::shared_ptr<pathtracer_result> run_on_device(const view_parameters& view, co
             // One iteration is one call: the interrupt flag is looked at between iterations (the reference looks
             // per scan line; an iteration is milliseconds here).  spi == 0 traces nothing, like the reference's
             // empty sample loop, and leaves the image as it is.
-            if (spi > 0) healthy = ok(ptk_group_render_iteration(group, seed, it, spi));
+            if (spi > 0)
+                healthy = ok(aov < 0 ? ptk_group_render_iteration(group, seed, it, spi)
+                                     : ptk_group_render_aov_iteration(group, uint32_t(aov), seed, it, spi));
             healthy = healthy && ok(ptk_group_read_image(group, reinterpret_cast<float*>(frame.data())));
             ptk_counters counters{};
             if (healthy && ptk_group_get_counters(group, &counters) == PTK_OK) {

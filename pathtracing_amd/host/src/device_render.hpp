@@ -20,10 +20,11 @@ struct device_run_info {
 // Flattens `scene` to a ptk_scene_desc and uploads it through the C ABI (include/ptk.h) on the caller's
 // thread -- or, when `session` already holds this scene, only sends the camera -- then starts the driver
 // thread that renders iteration by iteration on `devices` (one context each; ids may repeat).
+// aov >= 0 renders that debug AOV (PTK_AOV_*, include/ptk.h) instead of the integrator.
 // Never renders on the host: failures end the run and are reported by result->error().
 std::shared_ptr<pathtracer_result> run_on_device(const view_parameters& view, const trace_parameters& params, scene& scene,
                                                  const std::vector<int>& devices, uint64_t seed, uint64_t max_paths,
-                                                 std::shared_ptr<device_session> session, device_run_info* info);
+                                                 std::shared_ptr<device_session> session, device_run_info* info, int aov = -1);
 
 } // namespace detail
 } // namespace rt

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "device_render.hpp"
+#include "ptk_rt/utility.hpp"
 
 namespace rt {
 
@@ -166,6 +167,13 @@ std::shared_ptr<pathtracer_result> abstract_pathtracer::run(const view_parameter
         self.last_run.scene_reused = info.scene_reused;
         self.last_run.prepare_ms = info.prepare_ms;
         return result;
+    }
+    if (typeid(*this) == typeid(utility::debug_pathtracer) && static_cast<utility::debug_pathtracer&>(*this).use_device) {
+        // the reference's debug tracer (debug_pathtracer.cpp:8-32): its five modes are kernels of the library too
+        utility::debug_pathtracer& self = static_cast<utility::debug_pathtracer&>(*this);
+        if (!self.m_session) self.m_session = detail::make_device_session();
+        return detail::run_on_device(view_params, trace_params, scene, { self.device }, self.seed, 0, self.m_session, nullptr,
+                                     int(self.current_mode));
     }
     return std::make_shared<pathtracer_result>([this, view_params, trace_params, &scene](pathtracer_result& self) {
         host_driver(*this, view_params, trace_params, scene, self);

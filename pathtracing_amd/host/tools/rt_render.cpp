@@ -13,6 +13,7 @@
 //   rt_render --scene S --out image.bin [--resolution W H]
 //             [--iterations N] [--spp-per-iteration K] [--seed X] [--device D | --devices D0,D1,..]
 //             [--threads T] [--ldr-out rgba8.bin] [--interrupt-after N] [--asset-root DIR]
+//             [--aov albedo|emission|roughness|metallic|normal]   (rt::utility::debug_pathtracer instead of rt::pathtracer)
 //             [--then-camera PX PY PZ DX DY DZ --then-out image2.bin]   (a second run() on the same
 //              rt::pathtracer with only the camera moved: the Sandbox pattern, rtsb.cpp:295-299,355)
 //
@@ -28,6 +29,7 @@
 
 #include <pathtracer.h>
 #include <scene_loader.h>
+#include <debug_pathtracer.h>
 #include <unistd.h>
 
 namespace {
@@ -159,7 +161,7 @@ int main(int argc, char** argv)
     uint64_t interrupt_after = 0; // > 0: call interrupt() from the on_iteration_end handler (Sandbox-style stop)
     int device = 0;
     std::vector<int> devices;
-    std::string scene_file, out_file = "result.bin", ldr_file, asset_root, then_out;
+    std::string scene_file, out_file = "result.bin", ldr_file, asset_root, then_out, aov;
     bool then_camera = false;
     glm::vec3 then_pos(0.0f), then_dir(0.0f, 0.0f, -1.0f);
     for (int i = 1; i < argc; ++i) {
@@ -175,6 +177,7 @@ int main(int argc, char** argv)
         else if (p == "--device" && need(1)) device = std::stoi(argv[++i]);
         else if (p == "--interrupt-after" && need(1)) interrupt_after = std::stoull(argv[++i]);
         else if (p == "--asset-root" && need(1)) asset_root = argv[++i];
+        else if (p == "--aov" && need(1)) aov = argv[++i];
         else if (p == "--then-out" && need(1)) then_out = argv[++i];
         else if (p == "--devices" && need(1)) {
             const std::string list = argv[++i];
@@ -227,7 +230,20 @@ int main(int argc, char** argv)
     trace_params.iterations = iterations;
     trace_params.samples_per_iteration = spi;
 
-    auto result = pathtracer.run(view_params, trace_params, scene);
+    rt::utility::debug_pathtracer debug;
+    debug.device = device;
+    debug.seed = seed;
+    const char* const aov_names[5] = { "albedo", "emission", "roughness", "metallic", "normal" };
+    bool aov_known = aov.empty();
+    for (int k = 0; k < 5; ++k)
+        if (aov == aov_names[k]) {
+            debug.current_mode = static_cast<rt::utility::debug_pathtracer::mode>(k);
+            aov_known = true;
+        }
+    if (!aov_known) return fail("unknown --aov " + aov) ? 1 : 1;
+    rt::abstract_pathtracer& tracer = aov.empty() ? static_cast<rt::abstract_pathtracer&>(pathtracer) : debug;
+
+    auto result = tracer.run(view_params, trace_params, scene);
 
     uint64_t starts = 0, ends = 0;
     result->on_iteration_start.subscribe([&starts](const uint64_t&) { ++starts; });

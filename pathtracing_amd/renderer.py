@@ -113,6 +113,23 @@ class Context:
         self._check(self._lib.ptk_render_samples_noalloc_dev(self._h, seed, pixel_begin, pixel_count, sample_begin, sample_count,
                                                              sum_ptr, 1 if accumulate else 0))
 
+    def render_aov_dev(self, aov, seed, sample_begin, sample_count, sum_ptr, accumulate=False, pixel_begin=0, pixel_count=None):
+        """ptk_render_aov_dev: debug_pathtracer's AOVs (albedo, emission, roughness, metallic, normal) summed like samples."""
+        if pixel_count is None:
+            pixel_count = self.width * self.height - pixel_begin
+        self._check(self._lib.ptk_render_aov_dev(self._h, aov, seed, pixel_begin, pixel_count, sample_begin, sample_count,
+                                                 sum_ptr, 1 if accumulate else 0))
+
+    def render_aov_image(self, aov, seed, spp):
+        """(H, W, 3) mean AOV over spp jittered primary rays per pixel (host array)."""
+        n = self.width * self.height * 3
+        d_sum = self._to_dev(np.zeros(n, np.float32))
+        try:
+            self.render_aov_dev(aov, seed, 0, spp, d_sum)
+            return self._from_dev(d_sum, (self.height, self.width, 3), np.float32) / np.float32(spp)
+        finally:
+            self._free_dev(d_sum)
+
     def resolve_iteration_dev(self, sum_ptr, image_ptr, spi, iteration):
         self._check(self._lib.ptk_resolve_iteration_dev(self._h, sum_ptr, image_ptr, spi, iteration))
 

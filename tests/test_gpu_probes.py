@@ -178,3 +178,28 @@ def test_tonemap_exact(probe_ctx):
     assert (diff[~near] == 0).all(), np.argwhere((diff != 0) & ~near)[:5]
     assert diff.max() <= 1
     assert (diff != 0).mean() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["room", "materials", "mario"])
+def test_debug_aovs(gpu_ctx, name):
+    """ptk_render_aov_dev: rt::utility::debug_pathtracer::trace (debug_pathtracer.cpp:8-32) on the jittered primary rays, all
+    five modes, under every traversal mapping.  Same Philox jitter as the oracle, so every sample hits the same node:
+    colour-sampler channels are exact up to the order of the per-pixel sum, normals and Mario's texture lookups to 2e-5
+    (a pixel whose sample lands within rounding of a texel boundary aside)."""
+    from pathtracing_amd import _abi
+    ora = get_oracle(name)
+    gpu_ctx.upload(get_scene(name))
+    w, h, spp = 48, 40, 4
+    gpu_ctx.render_begin(w, h, np.pi / 4)
+    for aov in (_abi.PTK_AOV_ALBEDO, _abi.PTK_AOV_EMISSION, _abi.PTK_AOV_ROUGHNESS, _abi.PTK_AOV_METALLIC, _abi.PTK_AOV_NORMAL):
+        got = gpu_ctx.render_aov_image(aov, 9, spp)
+        ref = ora.render_aov(aov, w, h, np.pi / 4, 9, spp)
+        err = np.abs(got - ref).max(axis=2)
+        if name == "materials":   # the background is the equirect map (device atan2 / asin)
+            assert err.max() <= 2e-3 and (err <= 2e-5).mean() > 0.97, (aov, err.max())
+        elif name == "mario" and aov == _abi.PTK_AOV_ALBEDO:
+            assert (err <= 2e-5).mean() > 0.995 and err.max() < 0.5, (aov, err.max())
+        else:
+            assert err.max() <= 2e-5, (aov, err.max())
+    # the normal AOV really shows geometry: values spread over [0, 1]
+    assert ref.min() >= 0.0 and ref.max() <= 1.0 and ref.std() > 0.05

@@ -304,3 +304,21 @@ def test_rt_api_group_of_contexts_equals_one_context(tmp_path, devices, spi):
         imgs.append(np.fromfile(out_bin, dtype=np.float32))
     assert imgs[0].mean() > 0
     np.testing.assert_allclose(imgs[1], imgs[0], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aov,index", [("normal", 4), ("albedo", 0)])
+def test_debug_pathtracer_renders_on_the_gpu(tmp_path, aov, index):
+    """f4: rt::utility::debug_pathtracer (the reference's AOV tracer, debug_pathtracer.cpp:8-32) run through
+    abstract_pathtracer::run like Sandbox does (rtsb.cpp:301-305,378) is rendered by ptk_render_aov_dev."""
+    from conftest import ASSETS
+    out_bin = tmp_path / "aov.bin"
+    w, h = 40, 32
+    out = subprocess.run([_binary("rt_render"), "--scene", scene_path("room"), "--asset-root", ASSETS, "--out", str(out_bin),
+                          "--resolution", str(w), str(h), "--iterations", "1", "--spp-per-iteration", "1", "--seed", "4", "--aov", aov],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    img = np.fromfile(out_bin, dtype=np.float32).reshape(h, w, 3)
+    ref = get_oracle("room").render_aov(index, w, h, FOV, 4, 1)
+    assert np.abs(img - ref).max() <= 1e-4, np.abs(img - ref).max()
+    assert "paths=" in out.stdout

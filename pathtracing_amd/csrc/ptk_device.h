@@ -1005,9 +1005,9 @@ __device__ __forceinline__ void intersect_scene_nodelist(const DScene& S, V3 o, 
 //      test of a one-leaf mesh, whose survivors go to a second ring with their local ray;
 //   3. whenever 64 such candidates are stored, their triangles are dealt to the lanes two at
 //      a time (packed fp32: the two tests run in the two halves of v_pk_* operations, which
-//      are element-wise IEEE, so each half replays the scalar expression tree), grouped by
-//      triangle count so that no lane gets a padding item; then lane i finishes candidate i
-//      (hit -> world).
+//      are element-wise IEEE, so each half replays the scalar expression tree), 64 items
+//      at a time whatever the mix of leaf sizes, and only in whole chunks until the ray
+//      batch runs dry; then lane i finishes candidate i (hit -> world).
 // Results are combined with 64-bit LDS atomic minima on the keys the reference's strict `<`
 // loops imply: (squared local distance, leaf slot) inside a mesh (scene.cpp:196-202), (squared
 // world distance, node index) across nodes (scene.cpp:383-391).  Distances are non-negative
@@ -1028,8 +1028,9 @@ struct alignas(16) WaveLds {
     uint32_t st_first[128];          //   first leaf slot,
     uint32_t st_count[128];          //   triangle count,
     uint32_t st_item[128];           //   (node << 6 | owner lane)
-    uint32_t compact[64];            // window positions of the candidates in the current count group
+    uint32_t owner_at[64];           // triangle stage: item i of the chunk being filled, (pair << 6 | window position)
 };
+static_assert(sizeof(WaveLds) <= 10224, "k_bounce: four workgroups of four waves per CU (160 KB of LDS)");
 
 // value of `v` in lane `src` (every lane must be active)
 __device__ __forceinline__ float lane_get(float v, uint32_t src)
@@ -1048,6 +1049,24 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ uint32_t lane_get_u32(uint32_t v, uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+}
+
+// inclusive prefix sum over the 64 lanes (every lane active): four row_shr steps inside each row of 16, then the
+// row totals through row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3); lanes without a source add 0
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)v;
+}
 // Two triangles per lane: tri_eval on both halves of packed fp32 operations.
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct V3p {
@@ -1132,39 +1151,63 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         }
     };
 
-    // stage 3: triangles of the first `cnt` stored candidates, then their hit -> world
-    auto flush = [&](uint32_t cnt) {
+    // stage 3: triangles of the first `cnt` stored candidates, then their hit -> world.
+    // The (candidate, pair) items of the window are dealt 64 at a time in level order: first pair 0 of every
+    // candidate, then pair 1 of those that have one, and so on, whatever mix of leaf sizes the window holds.  Per
+    // level the candidates that still have a pair push (level, window position) into the next free slots of a
+    // 64-entry table (ballot + mbcnt); when the table is full, or nothing is left, lane i tests item i.  A chunk
+    // therefore holds a candidate twice only when fewer than 64 items are left on a level, which keeps the LDS
+    // minima below free of same-address collisions in the common case (and lets coherent waves read one triangle
+    // pair per chunk).
+    // Unless `all` is set only whole chunks are dealt: the window is cut back to the candidates that fill them (a
+    // prefix, by the running sum of the pair counts), the others stay in the ring until more have arrived, so that
+    // idle lanes appear only in a ray batch's last chunk.
+    auto flush = [&](uint32_t cnt, bool all) {
         [[maybe_unused]] const unsigned long long tc0 = PTK_CLOCK();
         PTK_STAT(S, 3, 1);
         wave_sync();
-        const bool have = lane < cnt;
         const uint32_t s = (shead + lane) & 127u;
-        const uint32_t my_pairs = have ? ((L.st_count[s] + 1u) >> 1) : 0u;
+        const uint32_t my_pairs = lane < cnt ? ((L.st_count[s] + 1u) >> 1) : 0u; // never 0 inside the window: empty leaves are not stored
+        if (!all) {
+            const uint32_t incl = wave_inclusive_sum(my_pairs);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total > 64u) {
+                const uint32_t whole = total & ~63u;
+                const uint32_t fit = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(lane < cnt && incl <= whole));
+                cnt = fit != 0u ? fit : 1u; // a first candidate larger than the whole chunks goes alone
+            }
+        }
+        const bool have = lane < cnt;
+        const uint32_t pairs = have ? my_pairs : 0u;
         L.cand_key[lane] = kKeyNone;
-        uint64_t todo = __builtin_amdgcn_ballot_w64(my_pairs != 0u);
-        while (todo != 0ull) {
-            // one group = the candidates with the same number of triangle pairs
-            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)my_pairs, (int)__builtin_ctzll(todo));
-            const uint64_t grp = __builtin_amdgcn_ballot_w64(my_pairs == v);
-            todo &= ~grp;
-            const uint32_t P = (uint32_t)__popcll(grp);
-            if (my_pairs == v) L.compact[mbcnt64(grp)] = lane;
+        uint32_t level = 0u, consumed = 0u, fill = 0u; // wave-uniform: current level, its candidates already dealt, slots taken
+        uint64_t mask = __builtin_amdgcn_ballot_w64(pairs > 0u);
+        while (mask != 0ull) {
+            const uint32_t P = (uint32_t)__popcll(mask), rank = mbcnt64(mask);
+            const uint32_t room = 64u - fill;
+            const uint32_t take = P - consumed < room ? P - consumed : room;
             wave_sync();
-            // item t = j * P + r: pair j of the group's r-th candidate; lane takes t = lane, lane + 64, ...
-            const uint32_t total = P * v;
-            uint32_t j = (uint32_t)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)P));
-            uint32_t r = lane - j * P;
-            const uint32_t dq = 64u / P, dr = 64u - dq * P;
-            PTK_STAT(S, 4, (total + 63u) / 64u);
-            PTK_STAT(S, 7, total);
-            for (uint32_t t0 = 0u; t0 < total; t0 += 64u) {
-                const bool valid = j < v;
-                const uint32_t c = L.compact[r];
+            if (pairs > level && rank - consumed < take) L.owner_at[fill + rank - consumed] = (level << 6) | lane;
+            fill += take;
+            consumed += take;
+            if (consumed == P) {
+                ++level;
+                consumed = 0u;
+                mask = __builtin_amdgcn_ballot_w64(pairs > level);
+            }
+            if (fill < 64u && mask != 0ull) continue;
+            wave_sync();
+            PTK_STAT(S, 4, 1);
+            PTK_STAT(S, 7, fill);
+            {
+                const bool valid = lane < fill;
+                const uint32_t it = valid ? L.owner_at[lane] : 0u;
+                const uint32_t c = it & 63u, j = it >> 6;
                 const uint32_t cs = (shead + c) & 127u;
                 const V3 co = mk(L.st_ray[0][cs], L.st_ray[1][cs], L.st_ray[2][cs]);
                 const V3 cd = mk(L.st_ray[3][cs], L.st_ray[4][cs], L.st_ray[5][cs]);
                 const uint32_t first_c = L.st_first[cs], count_c = L.st_count[cs];
-                const uint32_t k0 = valid ? 2u * j : 0u;
+                const uint32_t k0 = 2u * j;
                 const bool on_b = valid && k0 + 1u < count_c;
                 const uint32_t slot_a = first_c + k0, slot_b = slot_a + 1u; // first_c is even (ptk_scene_upload)
                 const float4* tp = S.tri_pair + (size_t)(slot_a >> 1) * 8;
@@ -1190,13 +1233,8 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
                     L.cand_pay[4][c] = take_b ? p2.y.y : p2.y.x;
                     L.cand_pay[5][c] = take_b ? p2.z.y : p2.z.x;
                 }
-                j += dq;
-                r += dr;
-                if (r >= P) {
-                    r -= P;
-                    ++j;
-                }
             }
+            fill = 0u;
         }
         wave_sync();
         const unsigned long long key = L.cand_key[lane];
@@ -1330,14 +1368,15 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         const float my_ed = lane_on ? fabsf(d.x - dc.x) + fabsf(d.y - dc.y) + fabsf(d.z - dc.z) : 0.0f;
         // wave maxima through LDS (non-negative floats order like their bit patterns); NaN -> no pre-cull
         const bool finite = !lane_on || (my_eo < 1e30f && my_ed < 1e30f);
-        L.compact[0] = 0u;
-        L.compact[1] = 0u;
+        uint32_t* const wave_max = L.owner_at; // free until the first triangle stage
+        wave_max[0] = 0u;
+        wave_max[1] = 0u;
         wave_sync();
-        atomicMax(&L.compact[0], __float_as_uint(my_eo));
-        atomicMax(&L.compact[1], __float_as_uint(my_ed));
+        atomicMax(&wave_max[0], __float_as_uint(my_eo));
+        atomicMax(&wave_max[1], __float_as_uint(my_ed));
         wave_sync();
-        eo = __uint_as_float(L.compact[0]);
-        ed = __uint_as_float(L.compact[1]);
+        eo = __uint_as_float(wave_max[0]);
+        ed = __uint_as_float(wave_max[1]);
         bundle_sane = __builtin_amdgcn_ballot_w64(!(finite && sane)) == 0ull && live != 0ull;
         wave_sync();
     }
@@ -1442,7 +1481,10 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         if (S.exp_stage == 1u || S.exp_stage == 2u) shead = stail;
         else
 #endif
-        if (sn >= 64u || (drained && sn != 0u)) flush(sn < 64u ? sn : 64u);
+        {
+            for (uint32_t w = sn; w >= 64u; w = stail - shead) flush(64u, false); // leaves fewer than 64 behind
+            if (drained && stail != shead) flush(stail - shead, true);
+        }
         if (drained && stail == shead) break;
     }
     PTK_STAT(S, 0, 1);
@@ -1482,11 +1524,6 @@ struct alignas(16) WalkLds {
     float stack_t[kWalkStack][64];     // ... and their distance bounds
 };
 
-__device__ __forceinline__ uint32_t lane_get_u32(uint32_t v, uint32_t src)
-{
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
-}
-
 // at_leaf: the lane stands on a leaf with triangles left to test.  Every lane of the wave calls this.
 __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool at_leaf, WalkLds& L)
 {
@@ -1495,12 +1532,7 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
     const uint32_t cnt = left < 64u ? left : 64u;
     const uint32_t first = W.leaf_base + W.ca + W.leaf_done; // slot of the lane's first triangle this stage
     // exclusive prefix sum of cnt over the lanes
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
-        incl += lane >= (uint32_t)off ? up : 0u;
-    }
+    const uint32_t incl = wave_inclusive_sum(cnt);
     const uint32_t start = incl - cnt;
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const uint64_t wm = __builtin_amdgcn_ballot_w64(cnt != 0u);

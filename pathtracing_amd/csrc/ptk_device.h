@@ -279,6 +279,38 @@ __device__ __forceinline__ bool box_intersect(float minx, float miny, float minz
     return slab_decide(t1, t2, t3, t4, t5, t6);
 }
 
+// bounding_box::intersect decided from approximate quotients, when that is certain.  q = (b - o) * rcp(d) is within
+// 2^-22 |q| of the IEEE quotient t the reference computes (b - o is the same subtraction; v_rcp_f32 is good to 1 ulp, the
+// product and the reference's divide to half an ulp each), and min / max keep such bounds, so with
+// delta = 5e-7 * max|q| + 1e-30 every entry distance e_a = min(q, q') and exit distance x_a = max(q, q') of an axis is
+// within delta of the reference's.  The reference accepts iff  t8 >= 0, t7 <= t8 and t7 != -1  with t7 = max_a e_a,
+// t8 = min_a x_a (scene.cpp:58-75).  t7 <= t8 means e_a <= x_b for all a, b; for a == b that holds by construction
+// (also for a flat box, where both are the same quotient), so only the pairs a != b need a margin:
+//   m_a = min(x_b, x_c) - e_a  must clear 2 delta,  t8' = min3(x) must clear delta,  t7' = max3(e) + 1 must clear delta,
+// and every quotient must be finite and below 1e30 (a zero or denormal direction component, NaN, overflow: undecided).
+// Returns the decision and sets `certain`; an undecided lane takes box_intersect.  A ray misses certainty only when it
+// passes within a relative 1e-6 of a box edge, so a wave rarely holds one.
+__device__ __forceinline__ bool box_intersect_fast(float minx, float miny, float minz, float maxx, float maxy, float maxz,
+                                                   V3 o, V3 d, bool& certain)
+{
+    const float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
+    const float q1 = (minx - o.x) * rx, q2 = (maxx - o.x) * rx;
+    const float q3 = (miny - o.y) * ry, q4 = (maxy - o.y) * ry;
+    const float q5 = (minz - o.z) * rz, q6 = (maxz - o.z) * rz;
+    const float ex = fminf(q1, q2), xx = fmaxf(q1, q2);
+    const float ey = fminf(q3, q4), xy = fmaxf(q3, q4);
+    const float ez = fminf(q5, q6), xz = fmaxf(q5, q6);
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(q1), fabsf(q2)), fabsf(q3)), fmaxf(fmaxf(fabsf(q4), fabsf(q5)), fabsf(q6)));
+    const float delta = __builtin_fmaf(5e-7f, big, 1e-30f);
+    const float mx = fminf(xy, xz) - ex, my = fminf(xx, xz) - ey, mz = fminf(xx, xy) - ez;
+    const float t8 = fminf(fminf(xx, xy), xz), t7 = fmaxf(fmaxf(ex, ey), ez);
+    const float m_lo = fminf(fminf(mx, my), mz);
+    const float m_abs = fminf(fminf(fabsf(mx), fabsf(my)), fabsf(mz));
+    // every comparison is written so that a NaN gives "not certain"
+    certain = (big < 1e30f) && (m_abs > 2.0f * delta) && (fabsf(t8) > delta) && (fabsf(t7 + 1.0f) > delta);
+    return m_lo >= 0.0f && t8 >= 0.0f;
+}
+
 // Closest-hit record carried through the node loop.  For a triangle a* holds the
 // barycentrics (u,v,w of scene.cpp:78-89); for a sphere it holds the local hit
 // position, from which normal and uv are rebuilt for the winner only.
@@ -1303,14 +1335,24 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         if (__builtin_amdgcn_ballot_w64(is_leaf) != 0ull) {
             // mesh::intersect on a root leaf: box test (scene.cpp:190); the triangles wait in the ring
             uint32_t count = 0u, first = 0u;
+            bool pass = false, undecided = false;
             if (is_leaf) {
                 const float4* __restrict__ lf = reinterpret_cast<const float4*>(S.leaf_info + n);
                 const float4 l0 = lf[0], l1 = lf[1];
-                if (box_intersect(l0.x, l0.y, l0.z, l1.x, l1.y, l1.z, lo, ld)) {
-                    count = __float_as_uint(l1.w);
-                    first = __float_as_uint(l0.w);
+                bool certain;
+                pass = box_intersect_fast(l0.x, l0.y, l0.z, l1.x, l1.y, l1.z, lo, ld, certain);
+                undecided = !certain;
+                count = __float_as_uint(l1.w);
+                first = __float_as_uint(l0.w);
+            }
+            if (__builtin_amdgcn_ballot_w64(undecided) != 0ull) { // rare: a lane within rounding of a box edge
+                if (undecided) {
+                    const float4* __restrict__ lf = reinterpret_cast<const float4*>(S.leaf_info + n);
+                    const float4 l0 = lf[0], l1 = lf[1];
+                    pass = box_intersect(l0.x, l0.y, l0.z, l1.x, l1.y, l1.z, lo, ld);
                 }
             }
+            if (!pass) count = 0u;
             const uint64_t pm = __builtin_amdgcn_ballot_w64(count != 0u);
             if (count != 0u) {
                 const uint32_t sl = (stail + mbcnt64(pm)) & 127u;

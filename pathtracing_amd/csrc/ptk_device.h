@@ -1298,6 +1298,10 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         const V3 ro = lane_get(o, owner), rd = lane_get(d, owner);
         const DNode* __restrict__ nd = S.nodes + n;
         const float4* __restrict__ nv = reinterpret_cast<const float4*>(nd);
+        // the root box of a one-leaf mesh is requested together with the matrix (same dependence: n), not when the
+        // leaf branch below needs it: one memory latency per batch instead of two
+        const float4* __restrict__ lf = reinterpret_cast<const float4*>(S.leaf_info + n);
+        const float4 l0 = lf[0], l1 = lf[1];
         V3 lo, ld;
         lane_ray_to_local(nv, ro, rd, lo, ld); // operator*(mat4, ray), scene.cpp:18-23
         const uint32_t cls = nd->cls;
@@ -1337,8 +1341,6 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             uint32_t count = 0u, first = 0u;
             bool pass = false, undecided = false;
             if (is_leaf) {
-                const float4* __restrict__ lf = reinterpret_cast<const float4*>(S.leaf_info + n);
-                const float4 l0 = lf[0], l1 = lf[1];
                 bool certain;
                 pass = box_intersect_fast(l0.x, l0.y, l0.z, l1.x, l1.y, l1.z, lo, ld, certain);
                 undecided = !certain;
@@ -1346,11 +1348,7 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
                 first = __float_as_uint(l0.w);
             }
             if (__builtin_amdgcn_ballot_w64(undecided) != 0ull) { // rare: a lane within rounding of a box edge
-                if (undecided) {
-                    const float4* __restrict__ lf = reinterpret_cast<const float4*>(S.leaf_info + n);
-                    const float4 l0 = lf[0], l1 = lf[1];
-                    pass = box_intersect(l0.x, l0.y, l0.z, l1.x, l1.y, l1.z, lo, ld);
-                }
+                if (undecided) pass = box_intersect(l0.x, l0.y, l0.z, l1.x, l1.y, l1.z, lo, ld);
             }
             if (!pass) count = 0u;
             const uint64_t pm = __builtin_amdgcn_ballot_w64(count != 0u);

@@ -1881,6 +1881,8 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     }
     // Pair table of the one-leaf meshes (intersect_scene_balanced): slots 2k and 2k+1 interleaved
     // word by word, so one 16-B load yields two packed-fp32 operands.  An odd tail repeats itself.
+    if (one_leaf_slots >= (size_t(1) << 26)) // the triangle stage packs a pair record's index in 25 bits
+        return fail(c, PTK_ERR_INVALID, "ptk_scene_upload: more than 2^26 triangles in one-leaf meshes");
     std::vector<float4> tri_pair(((one_leaf_slots + 1) / 2) * 8);
     for (size_t k = 0; k * 2 < one_leaf_slots; ++k) {
         const float* A = reinterpret_cast<const float*>(&tri_hit[(2 * k) * 4]);

@@ -1060,7 +1060,7 @@ struct alignas(16) WaveLds {
     uint32_t st_first[128];          //   first leaf slot,
     uint32_t st_count[128];          //   triangle count,
     uint32_t st_item[128];           //   (node << 6 | owner lane)
-    uint32_t owner_at[64];           // triangle stage: item i of the chunk being filled, (pair << 6 | window position)
+    uint32_t owner_at[64];           // triangle stage: item i of the chunk being filled (pair record, second-triangle flag, window position)
 };
 static_assert(sizeof(WaveLds) <= 10224, "k_bounce: four workgroups of four waves per CU (160 KB of LDS)");
 
@@ -1199,7 +1199,9 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         PTK_STAT(S, 3, 1);
         wave_sync();
         const uint32_t s = (shead + lane) & 127u;
-        const uint32_t my_pairs = lane < cnt ? ((L.st_count[s] + 1u) >> 1) : 0u; // never 0 inside the window: empty leaves are not stored
+        const uint32_t my_count = lane < cnt ? L.st_count[s] : 0u; // never 0 inside the window: empty leaves are not stored
+        const uint32_t my_pairs = (my_count + 1u) >> 1;
+        const uint32_t my_first = L.st_first[s] >> 1;              // first pair record (first slot is even, ptk_scene_upload)
         if (!all) {
             const uint32_t incl = wave_inclusive_sum(my_pairs);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1219,7 +1221,10 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             const uint32_t room = 64u - fill;
             const uint32_t take = P - consumed < room ? P - consumed : room;
             wave_sync();
-            if (pairs > level && rank - consumed < take) L.owner_at[fill + rank - consumed] = (level << 6) | lane;
+            // item = (pair record << 7 | pair has a second triangle << 6 | window position): everything the testing lane
+            // needs to request the record at once (pair records of one-leaf meshes < 2^25: ptk_scene_upload)
+            if (pairs > level && rank - consumed < take)
+                L.owner_at[fill + rank - consumed] = ((my_first + level) << 7) | (2u * level + 1u < my_count ? 64u : 0u) | lane;
             fill += take;
             consumed += take;
             if (consumed == P) {
@@ -1234,16 +1239,14 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             {
                 const bool valid = lane < fill;
                 const uint32_t it = valid ? L.owner_at[lane] : 0u;
-                const uint32_t c = it & 63u, j = it >> 6;
+                const uint32_t c = it & 63u, pair = it >> 7;
+                const float4* tp = S.tri_pair + (size_t)pair * 8;
+                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4], r5 = tp[5], r6 = tp[6], r7 = tp[7];
                 const uint32_t cs = (shead + c) & 127u;
                 const V3 co = mk(L.st_ray[0][cs], L.st_ray[1][cs], L.st_ray[2][cs]);
                 const V3 cd = mk(L.st_ray[3][cs], L.st_ray[4][cs], L.st_ray[5][cs]);
-                const uint32_t first_c = L.st_first[cs], count_c = L.st_count[cs];
-                const uint32_t k0 = 2u * j;
-                const bool on_b = valid && k0 + 1u < count_c;
-                const uint32_t slot_a = first_c + k0, slot_b = slot_a + 1u; // first_c is even (ptk_scene_upload)
-                const float4* tp = S.tri_pair + (size_t)(slot_a >> 1) * 8;
-                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4], r5 = tp[5], r6 = tp[6], r7 = tp[7];
+                const bool on_b = valid && (it & 64u) != 0u;
+                const uint32_t slot_a = 2u * pair, slot_b = slot_a + 1u;
                 bool hit_a, hit_b;
                 f2 dd2;
                 V3p bar2, p2;

@@ -49,6 +49,10 @@ static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
 namespace {
 
 constexpr int kBlock = 256;          // one queue segment = one workgroup = 4 waves
+// The split-mode kernels (k_bounce_split, k_walk_plan, k_walk, k_shade_parked, k_batch_parked) hand out a segment's
+// parked rays in quarters of 64 (unit = segment * 4 + quarter) and scan four wave counts per workgroup; the bounce
+// kernels' LDS budget (WaveLds) is sized for four waves per workgroup.  Another segment size needs those revisited.
+static_assert(kBlock == 256, "queue segment = 256 slots = four waves: quarter-segment walker units, 4-entry wave scans");
 constexpr int kStateFields = 13;     // o(3) d(3) T(3) L(3) path id
 constexpr uint64_t kDefaultMaxPaths = 1ull << 24;
 

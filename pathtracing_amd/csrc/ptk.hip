@@ -225,7 +225,8 @@ __device__ __forceinline__ void primary_ray(const DScene& S, const DView& V, con
 }
 
 template <bool FIRST, int MODE>
-__global__ __launch_bounds__(kBlock) void k_bounce(const DScene S, const DView V, const BounceArgs A)
+// at most 128 VGPRs (4 waves per SIMD, what LDS allows anyway), except for the variants that keep a KD stack in registers
+__global__ __launch_bounds__(kBlock, (MODE & 2) ? 1 : 4) void k_bounce(const DScene S, const DView V, const BounceArgs A)
 {
     __shared__ uint32_t wave_count[kBlock / 64];
     __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];

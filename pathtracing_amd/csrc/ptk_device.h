@@ -1385,6 +1385,7 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
     const V3 noi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     const float o1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
     const bool sane = o1 + (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)) < 1e8f; // false on NaN
+    const float lane_bias = !lane_on ? -__builtin_inff() : sane ? 0.0f : __builtin_inff();
     // Bundle pre-cull (BUNDLE): one test per node for the whole wave, 64 nodes at a time, lane = node.
     // Take the first live lane's ray (oc, dc) as the central ray and let eo = max |o_i - oc|_1,
     // ed = max |d_i - dc|_1 over the wave.  A ray i that reaches a point p of a node's padded world box
@@ -1498,10 +1499,13 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             const f2 tz = __builtin_elementwise_fma(f2{ cu->bz[0], cu->bz[1] } + pm, f2{ inv.z, inv.z }, f2{ noi.z, noi.z });
             const float t_in = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
             const float t_out = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
-            const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)); // false on NaN = keep
-            const bool facing_away =
-                __builtin_fmaf(d.x, cu->fn[0], __builtin_fmaf(d.y, cu->fn[1], d.z * cu->fn[2])) >= cu->ftau;
-            const bool keep = lane_on && !(sane && (missed || t_out < 0.0f || facing_away));
+            // the three reasons to drop a node as slacks that are negative when they apply: missed
+            // (t_in - t_out > 1e-5 (|t_in| + |t_out|)), behind (t_out < 0), facing away (d . fn > ftau); their minimum,
+            // plus the lane's bias (0; +inf for a ray that is never culled; -inf for a lane without a ray), decides in
+            // one compare, which the ballot below reads directly.  NaN compares as "keep".
+            const float ok_hit = __builtin_fmaf(1e-5f, fabsf(t_in) + fabsf(t_out), t_out - t_in);
+            const float ok_face = cu->ftau - __builtin_fmaf(d.x, cu->fn[0], __builtin_fmaf(d.y, cu->fn[1], d.z * cu->fn[2]));
+            const bool keep = !(fminf(fminf(ok_hit, t_out), ok_face) + lane_bias < 0.0f);
             if (SPLIT && cu->cls == kClassTree) { // wave-uniform branch
                 tree_mask |= keep ? (1ull << (cu->tree_slot & 63u)) : 0ull;
                 advance();

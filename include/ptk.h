@@ -327,7 +327,7 @@ int ptk_reset_counters(ptk_ctx* ctx);
  * tested in the uniform loop and each lane then visits only the nodes whose box it pierced;
  * 2 (default) = 0 for the coherent primary rays of bounce 0 (1 if PTK_OPT_NODE_CULL applies), 1 for
  * later bounces and for ptk_intersect_batch.  No reference counterpart. */
-enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5, PTK_OPT_DEVICE_KD = 6, PTK_OPT_WALK_STACK = 7 };
+enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5, PTK_OPT_DEVICE_KD = 6, PTK_OPT_WALK_STACK = 7, PTK_OPT_COMPACT = 8 };
 /* PTK_OPT_KD_PRUNE: how a multi-node KD-tree is walked (mesh::intersect_internal,
  * scene.cpp:188-212).  0 = the reference's order, every box-hit node is visited;
  * 1 (default) = near child first (by the sign of the ray direction on the split axis),
@@ -354,7 +354,12 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * PTK_OPT_WALK_STACK: how many pending far children the pruned KD walk may hold per ray before it sweeps the
  * current subtree without a stack (0..64; the kernels clamp it to their own short stack: 12 entries in LDS in the
  * walker kernel, 16 in the per-lane loops).  Default 64 = the kernels' capacity.  Small values only force the
- * stackless sweep (tests); results are identical for every value. */
+ * stackless sweep (tests); results are identical for every value.
+ * PTK_OPT_COMPACT: where the rays that survive a bounce are packed (scenes without KD-trees; split mode has its own
+ * queues).  0 = inside their 256-slot segment, in place; 1 = across segments, into a second queue (one more
+ * max_paths * 52 B of device memory, allocated on first use): after a bounce that ends most paths the next one then
+ * runs on full wavefronts; 2 (default) = 1.  The image does not depend on it (radiance is kept per path).
+ * ptk_render_samples_noalloc_dev always packs in place. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's

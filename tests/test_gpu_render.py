@@ -334,3 +334,32 @@ def test_converged_image_matches_independent_cpu_render(_gpu_ctx_session, name, 
     assert r <= 1e-3, r
     # means agree much tighter than single pixels
     assert abs(float(img.mean()) - float(ref.mean())) <= 0.01 * float(ref.mean()) + 1e-4
+
+
+@pytest.mark.parametrize("name", ["room", "materials", "furnace"])
+def test_compaction_across_segments_changes_nothing(gpu_ctx, name):
+    """PTK_OPT_COMPACT: survivors packed inside their segment (0) or across segments into the second queue (1).  Radiance
+    is kept per path and summed per pixel in a fixed order, so the image is bit-identical and so are the path / ray
+    counts; several chunks (small queue) and a ragged last segment included.  Auto (2) starts in place and may switch
+    once the counters of earlier calls have arrived: same image again."""
+    from pathtracing_amd import _abi
+    gpu_ctx.upload(get_scene(name))
+    w, h, spp = 53, 31, 24
+    out = {}
+    for mode, max_paths in ((0, 0), (1, 0), (1, 5000), (2, 0)):
+        gpu_ctx.set_option(_abi.PTK_OPT_COMPACT, mode)
+        gpu_ctx.render_begin(w, h, FOV, max_paths=max_paths)
+        gpu_ctx.reset_counters()
+        img = gpu_ctx.render_image(seed=11, iterations=3 if mode == 2 else 1, spi=spp)
+        out[(mode, max_paths)] = (img, gpu_ctx.counters())
+    gpu_ctx.set_option(_abi.PTK_OPT_COMPACT, 2)
+    ref_img, ref_counts = out[(0, 0)]
+    assert ref_counts[0] == w * h * spp and ref_counts[1] > ref_counts[0]
+    for key in ((1, 0), (1, 5000)):
+        assert np.array_equal(out[key][0], ref_img), key
+        assert out[key][1] == ref_counts, key
+    gpu_ctx.set_option(_abi.PTK_OPT_COMPACT, 0)
+    gpu_ctx.render_begin(w, h, FOV)
+    three = gpu_ctx.render_image(seed=11, iterations=3, spi=spp)
+    gpu_ctx.set_option(_abi.PTK_OPT_COMPACT, 2)
+    assert np.array_equal(out[(2, 0)][0], three)

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -78,6 +79,7 @@ struct ptk_group {
     std::vector<hipStream_t> stream; // per leader (same order as `leaders`): exchange step
     std::vector<ncclComm_t> comm;   // per leader, when there is more than one
     Rccl rccl;
+    bool use_rccl = false;          // more than one device, or PTK_GROUP_RCCL=1 (a one-device group then runs a one-rank reduce)
     uint32_t width = 0, height = 0;
     std::string err;
 };
@@ -161,7 +163,12 @@ int ptk_group_create(const int* device_ids, int n, ptk_group** out)
         }
         g->stream.push_back(s);
     }
-    if (g->leaders.size() > 1) { // more than one device: RCCL communicators, one per device
+    // More than one device: RCCL communicators, one per device.  PTK_GROUP_RCCL=1 asks for them with a single device
+    // too, so that a one-GPU machine can run the whole exchange path (library load, communicator, grouped reduce on
+    // the exchange stream) with one rank.
+    const char* force = std::getenv("PTK_GROUP_RCCL");
+    g->use_rccl = g->leaders.size() > 1 || (force && force[0] == '1');
+    if (g->use_rccl) {
         std::string err;
         if (!g->rccl.load(err)) {
             g_group_create_error = "ptk_group_create: " + err;
@@ -295,7 +302,7 @@ static int group_iteration(ptk_group* g, int aov, uint64_t seed, uint64_t iterat
         }
     }
     // step 2: one reduce(sum) of the per-device partial sums to member 0 over RCCL
-    if (g->leaders.size() > 1) {
+    if (g->use_rccl) {
         PTKG_NCCL(g, g->rccl.GroupStart());
         for (size_t i = 0; i < g->leaders.size(); ++i) {
             const int l = g->leaders[i];

@@ -324,6 +324,26 @@ def test_rt_api_group_of_contexts_equals_one_context(tmp_path, devices, spi):
 
 
 @pytest.mark.gpu
+def test_group_exchange_through_rccl_with_one_rank(tmp_path):
+    """The RCCL leg of the group's exchange step on a one-GPU box: PTK_GROUP_RCCL=1 makes a one-device group load RCCL
+    (dlopen), create its communicator (ncclCommInitAll over the one device) and run the grouped ncclReduce(sum) on the
+    exchange stream with a single rank, after the same-device members were folded.  The image must equal the run without
+    it.  What this cannot show is the reduce across several GPUs: no such box this round."""
+    txt = tmp_path / "room.txt"
+    write_scene_text(scene_path("room"), str(txt), str(tmp_path))
+    imgs = []
+    for env_extra in ({}, {"PTK_GROUP_RCCL": "1"}):
+        out_bin = tmp_path / f"img{len(imgs)}.bin"
+        out = subprocess.run([_binary("rt_render"), "--scene", str(txt), "--out", str(out_bin), "--resolution", "48", "40",
+                              "--iterations", "2", "--spp-per-iteration", "8", "--seed", "3", "--devices", "0,0"],
+                             capture_output=True, text=True, timeout=300, env={**os.environ, **env_extra})
+        assert out.returncode == 0, (out.stdout, out.stderr)
+        imgs.append(np.fromfile(out_bin, dtype=np.float32))
+    assert imgs[0].mean() > 0
+    assert np.array_equal(imgs[0], imgs[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("aov,index", [("normal", 4), ("albedo", 0)])
 def test_debug_pathtracer_renders_on_the_gpu(tmp_path, aov, index):
     """f4: rt::utility::debug_pathtracer (the reference's AOV tracer, debug_pathtracer.cpp:8-32) run through

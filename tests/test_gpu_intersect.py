@@ -384,3 +384,80 @@ def test_mirrored_and_sheared_planes(gpu_ctx):
     g, r = gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d)
     check_batch(g, r)
     assert (r["node"] >= 0).mean() > 0.2
+
+
+def test_rays_through_edges_and_corners_of_one_leaf_meshes(gpu_ctx):
+    """The root box test of a one-leaf mesh (bounding_box::intersect, scene.cpp:58-75) is decided from approximate
+    quotients when their error bounds allow it and by the six IEEE divides otherwise (box_intersect_fast).  Rays aimed
+    at the corners, edge points and face borders of a cube and a plane, exactly and a few ulps to either side, rays that
+    run inside a face plane, parallel to an axis, or start on a box plane, and rays whose entry distance is exactly -1
+    (the reference's `t9 != -1` quirk) sit on that boundary: ids must still be the oracle's, one for one."""
+    import os
+    from conftest import ASSETS
+    from oracle import oracle
+    from pathtracing_amd import scene as S
+    shapes = []
+    for f in ("cube.obj", "plane.obj"):
+        arrays = list(S.load_meshes_from_wavefront(os.path.join(ASSETS, "res", "meshes", f)).values())
+        shapes.append(S.Mesh(arrays[0]))
+    sc = S.Scene()
+    for k, shape in enumerate(shapes[:2]):
+        node = S.SceneNode()                      # identity: local space == world space, so the targets below are exact
+        node.shape = shape
+        sc.nodes.append(node)
+    tilted = S.SceneNode()
+    tilted.translate([4.0, 0.5, -1.0])
+    tilted.rotate([0.3, 1.0, 0.2], 0.7)
+    tilted.scale([0.5, 1.5, 0.75])
+    tilted.shape = shapes[0]
+    sc.nodes.append(tilted)
+    ora = oracle.OracleScene(sc)
+    gpu_ctx.upload(sc)
+    rng = np.random.default_rng(23)
+    lo = np.min([t.reshape(-1, 8)[:, 0:3].min(axis=0) for t in (shapes[0].triangles,)], axis=0)
+    hi = np.max([t.reshape(-1, 8)[:, 0:3].max(axis=0) for t in (shapes[0].triangles,)], axis=0)
+    grid = np.array([lo, (lo + hi) / 2, hi], dtype=np.float32)       # per axis: min, mid, max
+    pts = np.array([[grid[i, 0], grid[j, 1], grid[k, 2]] for i in range(3) for j in range(3) for k in range(3)], dtype=np.float32)
+    o_list, d_list = [], []
+    for rep in range(400):
+        o = rng.uniform(-4, 4, 3).astype(np.float32)
+        if rep % 5 == 0:
+            o[rng.integers(3)] = grid[rng.integers(3), 0]            # origin on a box plane
+        for p in pts:
+            t = p.copy()
+            for ax in range(3):                                       # exact, or 1..3 ulps off
+                steps = int(rng.integers(-3, 4))
+                for _ in range(abs(steps)):
+                    t[ax] = np.nextafter(t[ax], np.float32(np.inf if steps > 0 else -np.inf))
+            d = (t.astype(np.float64) - o.astype(np.float64))
+            n = np.linalg.norm(d)
+            if n < 1e-3:
+                continue
+            o_list.append(o)
+            d_list.append((d / n).astype(np.float32))
+    for rep in range(3000):                                           # axis-parallel and in-plane rays
+        o = rng.uniform(-3, 3, 3).astype(np.float32)
+        d = rng.normal(size=3)
+        ax = int(rng.integers(3))
+        d[ax] = 0.0
+        if rep % 2 == 0:
+            o[ax] = grid[rng.integers(3), ax]
+        if rep % 3 == 0:
+            d[(ax + 1) % 3] = 0.0
+        d /= np.linalg.norm(d)
+        o_list.append(o)
+        d_list.append(d.astype(np.float32))
+    for rep in range(2000):                                           # entry distance exactly -1 on some axis
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        d = d.astype(np.float32)
+        ax = int(rng.integers(3))
+        o = rng.uniform(-0.9, 0.9, 3).astype(np.float32)
+        o[ax] = np.float32(grid[0 if d[ax] > 0 else 2, ax] + d[ax])  # (plane - o) / d == -1 up to rounding
+        o_list.append(o)
+        d_list.append(d)
+    o = np.array(o_list, dtype=np.float32)
+    d = np.array(d_list, dtype=np.float32)
+    g, r = gpu_ctx.intersect_batch(o, d), ora.intersect_batch(o, d)
+    check_batch(g, r)
+    assert (r["node"] >= 0).sum() > 2000

@@ -12,6 +12,7 @@
 //
 //   rt_render --scene S --out image.bin [--resolution W H]
 //             [--iterations N] [--spp-per-iteration K] [--seed X] [--device D | --devices D0,D1,..]
+//             [--png-out image.png]   (what the reference CLI writes: CLI/main.cpp:85-107; needs stb_image_write.h on the include path at build time)
 //             [--threads T] [--ldr-out rgba8.bin] [--interrupt-after N] [--asset-root DIR]
 //             [--aov albedo|emission|roughness|metallic|normal]   (rt::utility::debug_pathtracer instead of rt::pathtracer)
 //             [--then-camera PX PY PZ DX DY DZ --then-out image2.bin]   (a second run() on the same
@@ -31,6 +32,12 @@
 #include <scene_loader.h>
 #include <debug_pathtracer.h>
 #include <unistd.h>
+#if __has_include(<stb_image_write.h>)
+// the reference vendors stb; the header is taken from the include path at build time (Makefile: STB_INC), never copied
+#define STB_IMAGE_WRITE_IMPLEMENTATION
+#include <stb_image_write.h>
+#define PTK_HAVE_STB_WRITE 1
+#endif
 
 namespace {
 
@@ -161,7 +168,7 @@ int main(int argc, char** argv)
     uint64_t interrupt_after = 0; // > 0: call interrupt() from the on_iteration_end handler (Sandbox-style stop)
     int device = 0;
     std::vector<int> devices;
-    std::string scene_file, out_file = "result.bin", ldr_file, asset_root, then_out, aov;
+    std::string scene_file, out_file = "result.bin", ldr_file, png_file, asset_root, then_out, aov;
     bool then_camera = false;
     glm::vec3 then_pos(0.0f), then_dir(0.0f, 0.0f, -1.0f);
     for (int i = 1; i < argc; ++i) {
@@ -170,6 +177,7 @@ int main(int argc, char** argv)
         if (p == "--scene" && need(1)) scene_file = argv[++i];
         else if (p == "--out" && need(1)) out_file = argv[++i];
         else if (p == "--ldr-out" && need(1)) ldr_file = argv[++i];
+        else if (p == "--png-out" && need(1)) png_file = argv[++i];
         else if (p == "--threads" && need(1)) threads = uint32_t(std::stoul(argv[++i]));
         else if (p == "--iterations" && need(1)) iterations = std::stoull(argv[++i]);
         else if (p == "--spp-per-iteration" && need(1)) spi = std::stoull(argv[++i]);
@@ -209,6 +217,7 @@ int main(int argc, char** argv)
         scene_file = absolute(scene_file);
         out_file = absolute(out_file);
         ldr_file = absolute(ldr_file);
+        png_file = absolute(png_file);
         then_out = absolute(then_out);
         if (!asset_root.empty() && chdir(asset_root.c_str()) != 0) return fail("cannot enter " + asset_root) ? 1 : 1;
         scene = rt::utility::load_scene(scene_file);
@@ -257,7 +266,7 @@ int main(int argc, char** argv)
     result->on_end.subscribe([&](const rt::image& image) {
         std::ofstream out(out_file, std::ios::binary);
         out.write(reinterpret_cast<const char*>(image.data()), std::streamsize(image.get_width() * image.get_height() * 12));
-        if (ldr_file.empty()) return;
+        if (ldr_file.empty() && png_file.empty()) return;
         // CLI/main.cpp:85-104: tone map, gamma, truncating 8-bit pack
         std::vector<uint32_t> pixels(image.get_height() * image.get_width());
         for (uint32_t x = 0; x < image.get_width(); ++x)
@@ -268,8 +277,18 @@ int main(int argc, char** argv)
                 pixels[y * image.get_width() + x] = (uint32_t(color.r * 255) << 0) | (uint32_t(color.g * 255) << 8) |
                                                     (uint32_t(color.b * 255) << 16) | (uint32_t(255) << 24);
             }
-        std::ofstream ldr(ldr_file, std::ios::binary);
-        ldr.write(reinterpret_cast<const char*>(pixels.data()), std::streamsize(pixels.size() * 4));
+        if (!ldr_file.empty()) {
+            std::ofstream ldr(ldr_file, std::ios::binary);
+            ldr.write(reinterpret_cast<const char*>(pixels.data()), std::streamsize(pixels.size() * 4));
+        }
+        if (!png_file.empty()) {
+#ifdef PTK_HAVE_STB_WRITE
+            if (!stbi_write_png(png_file.c_str(), int(image.get_width()), int(image.get_height()), 4, pixels.data(), 0)) // CLI/main.cpp:107
+                std::fprintf(stderr, "rt_render: cannot write %s\n", png_file.c_str());
+#else
+            std::fprintf(stderr, "rt_render: built without stb_image_write.h, --png-out ignored\n");
+#endif
+        }
     });
     result->wait();
 

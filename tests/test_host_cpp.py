@@ -324,6 +324,25 @@ def test_rt_api_group_of_contexts_equals_one_context(tmp_path, devices, spi):
 
 
 @pytest.mark.gpu
+def test_rt_render_writes_the_cli_png(tmp_path):
+    """--png-out: the file the reference CLI writes (tone map, gamma, truncating pack, stbi_write_png of RGBA rows in image
+    order, CLI/main.cpp:85-107), decoded here and compared with the packed pixels of --ldr-out."""
+    from PIL import Image as PILImage
+    txt = tmp_path / "room.txt"
+    write_scene_text(scene_path("room"), str(txt), str(tmp_path))
+    png, ldr, out_bin = tmp_path / "room.png", tmp_path / "ldr.bin", tmp_path / "img.bin"
+    out = subprocess.run([_binary("rt_render"), "--scene", str(txt), "--out", str(out_bin), "--ldr-out", str(ldr), "--png-out", str(png),
+                          "--resolution", "40", "24", "--iterations", "1", "--spp-per-iteration", "16", "--seed", "2"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert "--png-out ignored" not in out.stderr, "rt_render was built without stb_image_write.h"
+    rgba = np.fromfile(ldr, dtype=np.uint8).reshape(24, 40, 4)
+    decoded = np.asarray(PILImage.open(png).convert("RGBA"))
+    assert decoded.shape == rgba.shape and np.array_equal(decoded, rgba)
+    assert rgba[..., 3].min() == 255 and rgba[..., :3].std() > 5
+
+
+@pytest.mark.gpu
 def test_group_exchange_through_rccl_with_one_rank(tmp_path):
     """The RCCL leg of the group's exchange step on a one-GPU box: PTK_GROUP_RCCL=1 makes a one-device group load RCCL
     (dlopen), create its communicator (ncclCommInitAll over the one device) and run the grouped ncclReduce(sum) on the

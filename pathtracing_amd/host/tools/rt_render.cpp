@@ -169,6 +169,7 @@ int main(int argc, char** argv)
     int device = 0;
     std::vector<int> devices;
     std::string scene_file, out_file = "result.bin", ldr_file, png_file, asset_root, then_out, aov;
+    bool out_is_png = false;
     bool then_camera = false;
     glm::vec3 then_pos(0.0f), then_dir(0.0f, 0.0f, -1.0f);
     for (int i = 1; i < argc; ++i) {
@@ -207,6 +208,10 @@ int main(int argc, char** argv)
             return -1; // CLI/main.cpp:46-50
         }
     }
+
+    // `--out something.png` is the reference CLI's usage (CLI/main.cpp:19,29-32): the tone-mapped PNG, no raw image
+    out_is_png = out_file.size() > 4 && out_file.compare(out_file.size() - 4, 4, ".png") == 0;
+    if (out_is_png && png_file.empty()) png_file = out_file;
 
     rt::scene scene;
     if (scene_file.size() > 5 && scene_file.substr(scene_file.size() - 5) == ".json") {
@@ -264,8 +269,10 @@ int main(int argc, char** argv)
         if (interrupt_after && iteration + 1 >= interrupt_after) result->interrupt();
     });
     result->on_end.subscribe([&](const rt::image& image) {
-        std::ofstream out(out_file, std::ios::binary);
-        out.write(reinterpret_cast<const char*>(image.data()), std::streamsize(image.get_width() * image.get_height() * 12));
+        if (!out_is_png) {
+            std::ofstream out(out_file, std::ios::binary);
+            out.write(reinterpret_cast<const char*>(image.data()), std::streamsize(image.get_width() * image.get_height() * 12));
+        }
         if (ldr_file.empty() && png_file.empty()) return;
         // CLI/main.cpp:85-104: tone map, gamma, truncating 8-bit pack
         std::vector<uint32_t> pixels(image.get_height() * image.get_width());

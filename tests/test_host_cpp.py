@@ -340,6 +340,14 @@ def test_rt_render_writes_the_cli_png(tmp_path):
     decoded = np.asarray(PILImage.open(png).convert("RGBA"))
     assert decoded.shape == rgba.shape and np.array_equal(decoded, rgba)
     assert rgba[..., 3].min() == 255 and rgba[..., :3].std() > 5
+    # the reference CLI's own command line: --scene x.json --out y.png --iterations --resolution (CLI/main.cpp:21-45)
+    from conftest import ASSETS
+    png2 = tmp_path / "cli.png"
+    out = subprocess.run([_binary("rt_render"), "--scene", "res/scenes/room.json", "--out", str(png2), "--iterations", "1",
+                          "--resolution", "40", "24", "--threads", "4", "--spp-per-iteration", "16", "--seed", "2"],
+                         capture_output=True, text=True, timeout=300, cwd=ASSETS)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert np.array_equal(np.asarray(PILImage.open(png2).convert("RGBA")), rgba)
 
 
 @pytest.mark.gpu

@@ -1214,6 +1214,12 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         const bool have = lane < cnt;
         const uint32_t pairs = have ? my_pairs : 0u;
         L.cand_key[lane] = kKeyNone;
+        // the candidate's node -> world matrix and its ray's origin are requested now and used after the triangle
+        // chunks (hit -> world of the best triangle): the memory round trip runs under them
+        const uint32_t item = have ? L.st_item[s] : 0u;
+        const uint32_t owner = item & 63u, n_item = item >> 6;
+        const float4* __restrict__ nv_item = reinterpret_cast<const float4*>(S.nodes + n_item);
+        const float4 wx0 = nv_item[4], wx1 = nv_item[5], wx2 = nv_item[6], wx3 = nv_item[7];
         uint32_t level = 0u, consumed = 0u, fill = 0u; // wave-uniform: current level, its candidates already dealt, slots taken
         uint64_t mask = __builtin_amdgcn_ballot_w64(pairs > 0u);
         while (mask != 0ull) {
@@ -1275,16 +1281,16 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         const unsigned long long key = L.cand_key[lane];
         const bool found = have && key != kKeyNone;
         if (__builtin_amdgcn_ballot_w64(found) != 0ull) {
-            const uint32_t item = have ? L.st_item[s] : 0u;
-            const uint32_t owner = item & 63u, n = item >> 6;
             const V3 ro = lane_get(o, owner);
-            const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + n);
             const V3 bar = mk(L.cand_pay[0][lane], L.cand_pay[1][lane], L.cand_pay[2][lane]);
             const V3 p = mk(L.cand_pay[3][lane], L.cand_pay[4][lane], L.cand_pay[5][lane]);
-            V3 pw;
-            float d0;
-            lane_hit_to_world(nv, ro, p, pw, d0); // scene.cpp:375,383
-            commit(found, owner, d0, n, (int)(uint32_t)key, bar, pw);
+            // hit -> world (scene.cpp:375) + distance (scene.cpp:383), as lane_hit_to_world
+            const V3 pw = mk((wx0.x * p.x + wx1.x * p.y) + (wx2.x * p.z + wx3.x * 1.0f),
+                             (wx0.y * p.x + wx1.y * p.y) + (wx2.y * p.z + wx3.y * 1.0f),
+                             (wx0.z * p.x + wx1.z * p.y) + (wx2.z * p.z + wx3.z * 1.0f));
+            const V3 dv = pw - ro;
+            const float d0 = dot(dv, dv);
+            commit(found, owner, d0, n_item, (int)(uint32_t)key, bar, pw);
         }
         shead += cnt;
         PTK_STAT(S, 10, PTK_CLOCK() - tc0);

@@ -179,6 +179,14 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
         // pathtracer.cpp:67: miss -> background
         L = L + mulv(T, background_sample(S, d));
     } else {
+        // the two hemisphere draws need no memory: Philox is placed ahead of the attribute / sampler loads so that it can
+        // run under their round trips
+        float u1 = 0.0f, u2 = 0.0f;
+        if (A.bounce + 1 < PTK_MAX_DEPTH) {
+            const uint32_t pl = path / A.samples;
+            const uint32_t sm = path - pl * A.samples;
+            rng_pair(A.seed, (uint32_t)(A.pixel_begin + pl), A.sample_begin + sm, 1u + A.bounce, u1, u2);
+        }
         V3 n;
         float uvx, uvy, uu, vv;
         int prim_id;
@@ -192,10 +200,6 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
         const float metallic = sampler_sample(S, s_metallic, uvx, uvy).x;
         L = mk(__builtin_fmaf(T.x, emission.x, L.x), __builtin_fmaf(T.y, emission.y, L.y), __builtin_fmaf(T.z, emission.z, L.z));
         if (A.bounce + 1 < PTK_MAX_DEPTH) {
-            const uint32_t pl = path / A.samples;
-            const uint32_t sm = path - pl * A.samples;
-            float u1, u2;
-            rng_pair(A.seed, (uint32_t)(A.pixel_begin + pl), A.sample_begin + sm, 1u + A.bounce, u1, u2);
             // pathtracer.cpp:40-54
             const V3 hemi = hemisphere_dir(n, u1, u2);
             const V3 refl = sh_madd(n, -2.0f * sh_dot(n, d), d);

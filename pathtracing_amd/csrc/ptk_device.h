@@ -220,10 +220,9 @@ __device__ __forceinline__ V3 sh_mat_dir(const float* __restrict__ m, V3 p)
 
 // sin and cos of 2 pi u for the hemisphere sample (rng.cpp:29-31), shading only: one argument
 // reduction and two polynomials (error < 1e-7 on [0, 2 pi)) instead of the library's full-range
-// sinf and cosf, which differ from the host libm's in the last place just the same.  (The 1-ulp
-// hardware rsq / sqrt for the shading normalisations were tried as well: 3 % faster on Room, but
-// they add rounding differences to every bounce direction and the same-sample comparison with the
-// oracle drops below its calibrated 98 % of pixels, so the exact 1 / sqrt sequence stays.)
+// sinf and cosf, which differ from the host libm's in the last place just the same.  (Since round 2 the
+// shading normalisations use the 1-ulp hardware rsq / sqrt as well, see the sh_* helpers above; hit decisions
+// never do.)
 __device__ __forceinline__ void sincos_2pi_shade(float u, float& s, float& c)
 {
     // u in [0, 1): quarter turns q = round(4u) in {0..4}, r = 2 pi u - q pi/2 in [-pi/4, pi/4]

@@ -254,12 +254,15 @@ def main():
         finite = bool(torch.isfinite(image).all())
         assert finite and float(image.mean()) > 0.0, "render produced no radiance"
         assert paths == W * H * SPI * args.steps * world, (paths, W * H * SPI * args.steps * world)
+        wl_scene = WORKLOADS[args.workload]["scene"]
+        data_desc = (f"{wl_scene} (the reference's own scene file, src/res/scenes/{wl_scene}; no dataset or checkpoint involved)"
+                     if wl_scene else f"synthetic ({args.triangles}-triangle displaced sphere generated in code, workloads.synthetic_scene)")
         out = {
             "metric": "Mpaths/s", "value": paths / elapsed / 1e6, "unit": "Mpaths/s",
             "mrays_per_s": rays / elapsed / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "scene_upload_ms": upload_ms,
+            "vs_baseline": None, "dtype": "f32", "data": data_desc, "scene_upload_ms": upload_ms,
             "config": {"workload": f"{WORKLOADS[args.workload]['desc']}; {W}x{H}, {SPI} spp per GPU per step "
                                    "(one CLI iteration per GPU), fov pi/4, depth 5",
                        "paths_per_step_per_gpu": W * H * SPI, "rays_per_path": rays / paths,

@@ -358,7 +358,9 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * PTK_OPT_COMPACT: where the rays that survive a bounce are packed (scenes without KD-trees; split mode has its own
  * queues).  0 = inside their 256-slot segment, in place; 1 = across segments, into a second queue (one more
  * max_paths * 52 B of device memory, allocated on first use): after a bounce that ends most paths the next one then
- * runs on full wavefronts; 2 (default) = 1.  The image does not depend on it (radiance is kept per path).
+ * runs on full wavefronts; 2 (default) = decided per context from the rays per path of the chunks rendered so far
+ * (a snapshot of the counters behind each call): below 4 rays per path (an open scene) it packs across segments,
+ * otherwise in place.  The image does not depend on it (radiance is kept per path).
  * ptk_render_samples_noalloc_dev always packs in place. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 

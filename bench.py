@@ -5,9 +5,13 @@ Metric (BASELINE.json): Mpaths/s (+ Mrays/s) on the Room scene at 256x256.
 A step = one CLI iteration per GPU: every rank traces 256 samples per pixel of
 room.json at 256x256 (reference src/CLI/main.cpp:64-70: fov pi/4, 256 samples per
 iteration; depth 5) = 16.8 M paths, 83.9 M rays per GPU per step.  With N ranks the
-ranks take disjoint sample ranges of one N*256-spp iteration (weak scaling), their
-per-GPU HDR sum buffers are combined with one RCCL reduce to rank 0, and rank 0
-applies the running mean (abstract_pathtracer.cpp:88-90).  Scene tables and ray
+ranks take disjoint sample ranges of one N*256-spp iteration (weak scaling, the default),
+their per-GPU HDR sum buffers are combined with one RCCL reduce to rank 0, and rank 0
+applies the running mean (abstract_pathtracer.cpp:88-90).  --scaling strong keeps the
+job fixed instead, the way BASELINE.json's config 4 runs: ONE 256-spp iteration per step,
+each rank 256/N samples of every pixel.  Either way the reduce and the running mean run on
+a second stream under the next step's render (parallel.IterationPipeline: double-buffered
+sums, events, no host synchronisation inside the timed region).  Scene tables and ray
 queues are resident in HBM before the timed region; nothing crosses PCIe inside it.
 
 Prints ONE JSON line on rank 0 (see the round contract): value = whole-job Mpaths/s.
@@ -145,6 +149,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 path on a box with ONE GPU: every rank uses cuda:0 and the HDR sum "
                          "buffers are reduced through host memory (not a measurement)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank traces 256 spp per step; strong: one 256-spp iteration per step split "
+                         "over the ranks by sample range (config 4's shape)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="room")
     ap.add_argument("--triangles", type=int, default=5_000_000, help="synthetic workload: triangle count")
     ap.add_argument("--resolution", type=int, nargs=2, default=None)
@@ -183,11 +190,8 @@ def main():
                 keep.append(n)
         scene.nodes = keep
     ctx = Context(local_rank)
-    # one explicit stream for everything: the kernels of the library, torch's own ops and the point RCCL
-    # orders its reduce against (torch.distributed synchronises with the current stream)
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
+    # (the render and exchange streams are the pipeline's: parallel.IterationPipeline hands the render stream to the
+    # context and runs the reduce, which torch.distributed orders against the current stream, on the exchange stream)
     if args.traversal is not None:
         ctx.set_option(1, args.traversal)
     if args.kd_prune is not None:
@@ -205,23 +209,19 @@ def main():
     torch.cuda.synchronize(dev)
     upload_ms = (time.perf_counter() - t_up) * 1e3  # scene flattening + KD build + tables to HBM, outside the timed steps
     ctx.render_begin(W, H, FOV)
-    total = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
-    image = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
+    from pathtracing_amd import parallel
+    pipe = parallel.IterationPipeline(ctx, W, H, dev, rank, world, dist if distributed else None,
+                                      host_reduce=(args.backend == "gloo"))
+    # samples per pixel of one step over all ranks: weak = 256 per rank, strong = 256 in total (rank r renders the
+    # r-th part of the step's global sample range either way: parallel.iteration_share)
+    step_spi = SPI * world if args.scaling == "weak" else SPI
 
     def step(it):
-        # rank r traces global samples [(it*world + r)*SPI, +SPI) of every pixel
-        ctx.render_samples_dev(0, (it * world + rank) * SPI, SPI, total.data_ptr())
-        if distributed and args.backend == "gloo":
-            host = total.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            total.copy_(host)
-        elif distributed:
-            dist.reduce(total, dst=0, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            ctx.resolve_iteration_dev(total.data_ptr(), image.data_ptr(), SPI * world, it)
+        pipe.step(it, step_spi, seed=0)
 
     for it in range(args.warmup):
         step(it)
+    pipe.synchronize()
     torch.cuda.synchronize(dev)
     ctx.reset_counters()
     ctx.enable_timing(True)
@@ -231,11 +231,15 @@ def main():
     t0 = time.perf_counter()
     for it in range(args.steps):
         step(args.warmup + it)
+    pipe.synchronize()
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    image = pipe.image
+    # ranks that took part in the exchange (RCCL when the backend is nccl), read after the first reduce has run
+    rccl_ranks = dist.get_world_size() if (distributed and pipe.reduces > 0) else 1
 
     paths, rays = ctx.counters()
     timing = ctx.timing()
@@ -253,7 +257,7 @@ def main():
     if rank == 0:
         finite = bool(torch.isfinite(image).all())
         assert finite and float(image.mean()) > 0.0, "render produced no radiance"
-        assert paths == W * H * SPI * args.steps * world, (paths, W * H * SPI * args.steps * world)
+        assert paths == W * H * step_spi * args.steps, (paths, W * H * step_spi * args.steps)
         wl_scene = WORKLOADS[args.workload]["scene"]
         data_desc = (f"{wl_scene} (the reference's own scene file, src/res/scenes/{wl_scene}; no dataset or checkpoint involved)"
                      if wl_scene else f"synthetic ({args.triangles}-triangle displaced sphere generated in code, workloads.synthetic_scene)")
@@ -261,12 +265,16 @@ def main():
             "metric": "Mpaths/s", "value": paths / elapsed / 1e6, "unit": "Mpaths/s",
             "mrays_per_s": rays / elapsed / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "rccl_ranks": rccl_ranks if args.backend == "nccl" else None,
             "vs_baseline": None, "dtype": "f32", "data": data_desc, "scene_upload_ms": upload_ms,
-            "config": {"workload": f"{WORKLOADS[args.workload]['desc']}; {W}x{H}, {SPI} spp per GPU per step "
-                                   "(one CLI iteration per GPU), fov pi/4, depth 5",
-                       "paths_per_step_per_gpu": W * H * SPI, "rays_per_path": rays / paths,
-                       "parallelism": f"sample-range x{world}" + (" + RCCL reduce(sum) to rank 0" if distributed else "")},
+            "config": {"workload": f"{WORKLOADS[args.workload]['desc']}; {W}x{H}, " +
+                                   (f"{SPI} spp per GPU per step (one CLI iteration per GPU)" if args.scaling == "weak"
+                                    else f"{SPI} spp per step over all GPUs (one CLI iteration split by sample range)") +
+                                   ", fov pi/4, depth 5",
+                       "paths_per_step_per_gpu": W * H * step_spi // world, "rays_per_path": rays / paths,
+                       "parallelism": f"sample-range x{world}" + (" + RCCL reduce(sum) to rank 0 on a second stream, "
+                                                                  "double-buffered sums" if distributed else "")},
         }
         model = None
         model_tables = {"kd_bytes": 0}

@@ -35,6 +35,7 @@ extern "C" {
 #define PTK_ERR_HIP 2       /* a HIP runtime call failed (see ptk_last_error)  */
 #define PTK_ERR_STATE 3     /* call made in the wrong order (no scene, ...)     */
 #define PTK_ERR_NOMEM 4
+#define PTK_INTERRUPTED 5   /* not an error: the call stopped early on ptk_request_interrupt / ptk_group_request_interrupt */
 
 #define PTK_MAX_DEPTH 5u        /* pathtracer.cpp:16  trace_recursive(..., 5)    */
 #define PTK_EPSILON 1e-3f       /* pathtracer.h:19    s_epsilon                  */
@@ -163,7 +164,15 @@ void ptk_ctx_destroy(ptk_ctx* ctx);
 const char* ptk_last_error(const ptk_ctx* ctx);
 /* Use `hip_stream` (a hipStream_t) for all later work; NULL = the context's own. */
 int ptk_ctx_set_stream(ptk_ctx* ctx, void* hip_stream);
+/* The hipStream_t later work is enqueued on (the context's own unless ptk_ctx_set_stream changed it). */
+void* ptk_ctx_get_stream(ptk_ctx* ctx);
 int ptk_ctx_synchronize(ptk_ctx* ctx);
+/* pathtracer_result::interrupt (abstract_pathtracer.h:150; the flag the driver's loops poll,
+ * abstract_pathtracer.cpp:38,63,68,72).  May be called from any thread while another thread is inside
+ * ptk_render_image on the same context: that call stops before its next launch chain (it hands the GPU at most
+ * max_paths_per_launch paths at a time, two chains in flight), folds the pixels finished so far into the image
+ * and returns PTK_INTERRUPTED.  A request with no ptk_render_image running is served by the next one. */
+int ptk_request_interrupt(ptk_ctx* ctx);
 
 /* ---- scene ---------------------------------------------------------------
  * Replaces scene::compile (scene.cpp:331-348) -> mesh::compile
@@ -280,8 +289,15 @@ int ptk_render_aov_dev(ptk_ctx* ctx, uint32_t aov, uint64_t seed,
 int ptk_resolve_iteration_dev(ptk_ctx* ctx, const float* sum_rgb_dev, float* image_rgb_dev,
                               uint64_t samples_per_iteration, uint64_t iteration);
 
+/* The same over the pixels [pixel_begin, pixel_begin + pixel_count) only: what the driver does with an
+ * interrupted iteration, whose unfinished scan lines keep the previous mean (abstract_pathtracer.cpp:63-72,109). */
+int ptk_resolve_range_dev(ptk_ctx* ctx, const float* sum_rgb_dev, float* image_rgb_dev,
+                          uint64_t pixel_begin, uint64_t pixel_count,
+                          uint64_t samples_per_iteration, uint64_t iteration);
+
 /* Convenience for single-GPU hosts: runs `iterations` full iterations
- * (abstract_pathtracer.cpp:38-112, without events) into a host image. */
+ * (abstract_pathtracer.cpp:38-112, without events) into a host image.  Returns PTK_INTERRUPTED (image valid,
+ * last iteration partial) after ptk_request_interrupt. */
 int ptk_render_image(ptk_ctx* ctx, uint64_t seed, uint64_t iterations,
                      uint32_t samples_per_iteration, float* image_rgb);
 
@@ -320,6 +336,10 @@ int ptk_probe_shade_dev(ptk_ctx* ctx, uint64_t n, const float* origins_dev, cons
 /* Device ray / path counters since the last reset (synchronises). */
 int ptk_get_counters(ptk_ctx* ctx, ptk_counters* out);
 int ptk_reset_counters(ptk_ctx* ctx);
+/* The same without waiting: the counters are copied to host_out (pinned host memory, for a copy that really is
+ * asynchronous) behind the work already enqueued on the context's stream; host_out is valid once that stream, or
+ * an event recorded on it after this call, has completed. */
+int ptk_counters_download_async(ptk_ctx* ctx, ptk_counters* host_out);
 
 /* Tuning switches (results are identical for every value; tests run both).
  * PTK_OPT_TRAVERSAL: how scene::cast_ray's node loop (scene.cpp:361-395) is mapped to a
@@ -428,13 +448,44 @@ int ptk_group_render_begin(ptk_group* group, uint32_t width, uint32_t height, fl
                            uint64_t max_paths_per_launch);
 /* One iteration of the driver loop (abstract_pathtracer.cpp:38-112): global samples
  * [iteration * spi, (iteration + 1) * spi) of every pixel, split over the members, reduced to
- * member 0 and folded into its running-mean image.  Synchronises. */
+ * member 0 and folded into its running-mean image.  Synchronises.  Inside, the iteration goes to the GPUs in
+ * slices (below) with two in flight; ptk_group_request_interrupt from another thread stops it before the next
+ * slice: the pixels of the finished slices are folded into the image, the others keep the previous mean (the
+ * reference's unfinished scan lines, abstract_pathtracer.cpp:63-72,109) and the call returns PTK_INTERRUPTED.
+ * ptk_group_progress = finished slices / slices of the running iteration (pathtracer_result::progress,
+ * abstract_pathtracer.cpp:51).  ptk_group_render_begin clears the interrupt request. */
 int ptk_group_render_iteration(ptk_group* group, uint64_t seed, uint64_t iteration,
                                uint64_t samples_per_iteration);
 /* The same with ptk_render_aov_dev in place of ptk_render_samples_dev (aov = PTK_AOV_*). */
 int ptk_group_render_aov_iteration(ptk_group* group, uint32_t aov, uint64_t seed, uint64_t iteration,
                                    uint64_t samples_per_iteration);
-/* Member 0's running-mean image -> host (width*height*3 floats, row 0 = top). */
+int ptk_group_request_interrupt(ptk_group* group);
+float ptk_group_progress(const ptk_group* group);
+
+/* The iteration in asynchronous steps, for a driver that keeps the GPUs busy while it handles the previous
+ * iteration (on_iteration_end handlers, abstract_pathtracer.cpp:109) and decides itself when to stop:
+ *   ptk_group_iteration_slices   how many slices an iteration of spi samples has: pixel ranges sized so that every
+ *                                member's part of a slice is one launch chain (<= max_paths_per_launch paths);
+ *   ptk_group_submit_slice       enqueues one slice on every member (aov < 0: the integrator, else PTK_AOV_*) and
+ *                                returns a ticket; never waits for the GPU;
+ *   ptk_group_wait_slice         blocks until every member has finished the slice of that ticket (one of the last
+ *                                8 submitted);
+ *   ptk_group_finish_iteration   enqueues the exchange (add on shared devices, ncclReduce to member 0) behind the
+ *                                members' slices, the running mean over the pixels of the first slices_done
+ *                                slices (slices_done < num_slices: an interrupted iteration) and, if download is set,
+ *                                the copy of the image to pinned host memory; never waits.  The sum images are
+ *                                double-buffered by iteration parity: slices of iteration i + 1 may be submitted
+ *                                before or after this call for iteration i, slices of iteration i + 2 only after it;
+ *   ptk_group_wait_iteration     blocks until that iteration has been resolved; copies the image (if it was
+ *                                downloaded and image_rgb is not NULL) and the members' summed counters out. */
+int ptk_group_iteration_slices(ptk_group* group, uint64_t samples_per_iteration, uint32_t* num_slices);
+int ptk_group_submit_slice(ptk_group* group, int aov, uint64_t seed, uint64_t iteration, uint64_t samples_per_iteration,
+                           uint32_t slice, uint32_t num_slices, uint64_t* ticket);
+int ptk_group_wait_slice(ptk_group* group, uint64_t ticket);
+int ptk_group_finish_iteration(ptk_group* group, uint64_t iteration, uint64_t samples_per_iteration,
+                               uint32_t slices_done, uint32_t num_slices, int download);
+int ptk_group_wait_iteration(ptk_group* group, uint64_t iteration, float* image_rgb, ptk_counters* counters);
+/* Member 0's running-mean image -> host (width*height*3 floats, row 0 = top).  Waits for the iterations finished so far. */
 int ptk_group_read_image(ptk_group* group, float* image_rgb);
 /* Sum of the members' counters. */
 int ptk_group_get_counters(ptk_group* group, ptk_counters* out);

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTK_LIB") or os.path.join(_HERE, "libptk.so")
 
 PTK_OK = 0
+PTK_INTERRUPTED = 5
 PTK_ERR_INVALID, PTK_ERR_HIP, PTK_ERR_STATE, PTK_ERR_NOMEM = 1, 2, 3, 4
 PTK_MAX_DEPTH = 5
 PTK_AOV_ALBEDO, PTK_AOV_EMISSION, PTK_AOV_ROUGHNESS, PTK_AOV_METALLIC, PTK_AOV_NORMAL = range(5)
@@ -128,6 +129,17 @@ SYMBOLS = {
     "ptk_last_error": (C.c_char_p, [C.c_void_p]),
     "ptk_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ptk_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "ptk_ctx_get_stream": (C.c_void_p, [C.c_void_p]),
+    "ptk_request_interrupt": (C.c_int, [C.c_void_p]),
+    "ptk_resolve_range_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "ptk_counters_download_async": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ptk_group_request_interrupt": (C.c_int, [C.c_void_p]),
+    "ptk_group_progress": (C.c_float, [C.c_void_p]),
+    "ptk_group_iteration_slices": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "ptk_group_submit_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "ptk_group_wait_slice": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "ptk_group_finish_iteration": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
+    "ptk_group_wait_iteration": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Counters)]),
     "ptk_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "ptk_scene_set_camera": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc)]),
     "ptk_kd_build": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(KdInfo), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),

@@ -18,6 +18,7 @@
 // throughput) writes its radiance once to sample_L[path id].
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -968,6 +969,7 @@ struct ptk_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
+    std::atomic<int> interrupt{ 0 }; // ptk_request_interrupt: looked at by ptk_render_image between launch chains
 
     // scene tables in HBM
     std::vector<void*> allocs;      // scene allocations
@@ -1720,6 +1722,15 @@ int ptk_ctx_set_stream(ptk_ctx* c, void* hip_stream)
     return PTK_OK;
 }
 
+void* ptk_ctx_get_stream(ptk_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int ptk_request_interrupt(ptk_ctx* c)
+{
+    if (!c) return PTK_ERR_INVALID;
+    c->interrupt = 1;
+    return PTK_OK;
+}
+
 int ptk_ctx_synchronize(ptk_ctx* c)
 {
     if (!c) return PTK_ERR_INVALID;
@@ -2437,18 +2448,29 @@ int ptk_render_aov_dev(ptk_ctx* c, uint32_t aov, uint64_t seed, uint64_t pixel_b
     return PTK_OK;
 }
 
-int ptk_resolve_iteration_dev(ptk_ctx* c, const float* sum_rgb, float* image_rgb, uint64_t spi, uint64_t iteration)
+int ptk_resolve_range_dev(ptk_ctx* c, const float* sum_rgb, float* image_rgb, uint64_t pixel_begin, uint64_t pixel_count,
+                          uint64_t spi, uint64_t iteration)
 {
     if (!c) return PTK_ERR_INVALID;
     if (!c->has_view) return fail(c, PTK_ERR_STATE, "ptk_resolve_iteration: call ptk_render_begin first");
     if (!sum_rgb || !image_rgb || spi == 0) return fail(c, PTK_ERR_INVALID, "ptk_resolve_iteration: bad arguments");
+    const uint64_t num_pixels = (uint64_t)c->V.width * c->V.height;
+    if (pixel_begin > num_pixels || pixel_count > num_pixels - pixel_begin)
+        return fail(c, PTK_ERR_INVALID, "ptk_resolve_iteration: pixel range outside the viewport");
+    if (pixel_count == 0) return PTK_OK;
     if (int r = set_device(c)) return r;
-    const uint64_t n = (uint64_t)c->V.width * c->V.height * 3;
+    const uint64_t n = pixel_count * 3;
     const float t = (float)iteration / (float)(iteration + 1);
-    hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sum_rgb,
-                       image_rgb, n, (float)spi, t);
+    hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sum_rgb + pixel_begin * 3,
+                       image_rgb + pixel_begin * 3, n, (float)spi, t);
     PTK_HIP(c, hipGetLastError());
     return PTK_OK;
+}
+
+int ptk_resolve_iteration_dev(ptk_ctx* c, const float* sum_rgb, float* image_rgb, uint64_t spi, uint64_t iteration)
+{
+    if (!c) return PTK_ERR_INVALID;
+    return ptk_resolve_range_dev(c, sum_rgb, image_rgb, 0, (uint64_t)c->V.width * c->V.height, spi, iteration);
 }
 
 int ptk_render_image(ptk_ctx* c, uint64_t seed, uint64_t iterations, uint32_t spi, float* image_rgb)
@@ -2465,9 +2487,35 @@ int ptk_render_image(ptk_ctx* c, uint64_t seed, uint64_t iterations, uint32_t sp
     int rc = PTK_OK;
     hipError_t e = hipMemsetAsync(d_img, 0, np * 3 * sizeof(float), c->stream);
     if (e != hipSuccess) rc = fail(c, PTK_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
-    for (uint64_t it = 0; it < iterations && rc == PTK_OK; ++it) {
-        rc = ptk_render_samples_dev(c, seed, 0, np, it * spi, spi, d_sum, 0);
-        if (rc == PTK_OK) rc = ptk_resolve_iteration_dev(c, d_sum, d_img, spi, it);
+    // One launch chain (at most max_paths_per_launch paths) at a time is handed to the GPU, two in flight: between
+    // chains the interrupt flag is looked at, as the reference looks per scan line (abstract_pathtracer.cpp:63-72).
+    // An interrupted iteration folds the pixels it finished into the image (the other pixels keep the previous
+    // iterations' mean, like the reference's unfinished scan lines) and the call returns PTK_INTERRUPTED.
+    hipEvent_t ev[2] = { nullptr, nullptr };
+    for (int i = 0; i < 2 && rc == PTK_OK; ++i)
+        if ((e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)) != hipSuccess)
+            rc = fail(c, PTK_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+    const uint64_t per_pixel = (uint64_t)spi < c->cap ? spi : c->cap;
+    const uint64_t budget = c->cap / per_pixel; // pixels per chain
+    bool interrupted = false;
+    uint64_t chains = 0;
+    for (uint64_t it = 0; it < iterations && rc == PTK_OK && !interrupted; ++it) {
+        uint64_t done = 0;
+        for (uint64_t p0 = 0; p0 < np && rc == PTK_OK; p0 += budget) {
+            if (c->interrupt.load()) {
+                interrupted = true;
+                break;
+            }
+            const uint64_t cnt = np - p0 < budget ? np - p0 : budget;
+            if (chains >= 2 && (e = hipEventSynchronize(ev[chains & 1])) != hipSuccess)
+                rc = fail(c, PTK_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+            if (rc == PTK_OK) rc = ptk_render_samples_dev(c, seed, p0, cnt, it * spi, spi, d_sum, 0);
+            if (rc == PTK_OK && (e = hipEventRecord(ev[chains & 1], c->stream)) != hipSuccess)
+                rc = fail(c, PTK_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
+            ++chains;
+            done = p0 + cnt;
+        }
+        if (rc == PTK_OK) rc = ptk_resolve_range_dev(c, d_sum, d_img, 0, done, spi, it);
     }
     if (rc == PTK_OK) {
         e = hipMemcpyAsync(image_rgb, d_img, np * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
@@ -2475,8 +2523,11 @@ int ptk_render_image(ptk_ctx* c, uint64_t seed, uint64_t iterations, uint32_t sp
     }
     e = hipStreamSynchronize(c->stream);
     if (rc == PTK_OK && e != hipSuccess) rc = fail(c, PTK_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    for (int i = 0; i < 2; ++i)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
     (void)hipFree(buf);
-    return rc;
+    c->interrupt = 0; // the request has been served (or came too late for this call)
+    return (rc == PTK_OK && interrupted) ? PTK_INTERRUPTED : rc;
 }
 
 int ptk_tonemap_dev(ptk_ctx* c, const float* image_rgb, uint32_t* rgba8, uint64_t num_pixels)
@@ -2554,6 +2605,15 @@ int ptk_probe_shade_dev(ptk_ctx* c, uint64_t n, const float* origins, const floa
     }
 #undef PTK_PROBE
     PTK_HIP(c, hipGetLastError());
+    return PTK_OK;
+}
+
+int ptk_counters_download_async(ptk_ctx* c, ptk_counters* host_out)
+{
+    if (!c || !host_out) return PTK_ERR_INVALID;
+    if (int r = set_device(c)) return r;
+    static_assert(sizeof(ptk_counters) == 2 * sizeof(unsigned long long), "ptk_counters = the two device counters");
+    PTK_HIP(c, hipMemcpyAsync(host_out, c->d_counters, sizeof(ptk_counters), hipMemcpyDeviceToHost, c->stream));
     return PTK_OK;
 }
 

@@ -339,25 +339,94 @@ std::shared_ptr<pathtracer_result> run_on_device(const view_parameters& view, co
         };
         bool healthy = num_pixels > 0 && ok(ptk_group_render_begin(group, view.width, view.height, view.fov_y, max_paths));
         const uint64_t spi = params.samples_per_iteration;
-        for (uint64_t it = 0; healthy && (params.iterations == 0 || it < params.iterations) && !self.is_interrupted(); ++it) {
-            self.on_iteration_start(it);
-            // One iteration is one call: the interrupt flag is looked at between iterations (the reference looks
-            // per scan line; an iteration is milliseconds here).  spi == 0 traces nothing, like the reference's
-            // empty sample loop, and leaves the image as it is.
-            if (spi > 0)
-                healthy = ok(aov < 0 ? ptk_group_render_iteration(group, seed, it, spi)
-                                     : ptk_group_render_aov_iteration(group, uint32_t(aov), seed, it, spi));
-            healthy = healthy && ok(ptk_group_read_image(group, reinterpret_cast<float*>(frame.data())));
+        uint32_t K = 1; // slices per iteration (pixel ranges of one launch chain each)
+        if (healthy && spi > 0) healthy = ok(ptk_group_iteration_slices(group, spi, &K));
+
+        // The reference's driver (abstract_pathtracer.cpp:27-112) as a pipeline.  Slices are submitted ahead of the
+        // GPU (kWindow in flight, across iteration boundaries), so the frame download and the handlers of iteration i
+        // run while the GPU renders iteration i + 1; the handlers still see start(i), end(i), start(i + 1), ... in
+        // order.  The interrupt flag is looked at before every submission (the reference: per scan line, pixel and
+        // sample, :63-72), progress follows the finished slices (:51).  After an interrupt nothing more is submitted;
+        // the iteration that is open ends with the slices it got (at most kWindow launch chains are still in flight):
+        // one that got only part of them is resolved over those pixels, the others keep the previous mean, and
+        // on_iteration_end / on_end fire as the reference fires them (:109,114).  No further iteration opens (:38).
+        constexpr uint32_t kWindow = 2;
+        const auto wanted = [&](uint64_t it) { return params.iterations == 0 || it < params.iterations; };
+        uint64_t sub_it = 0, done_it = 0;   // iteration of the next slice to submit / to wait for
+        uint32_t sub_k = 0, done_k = 0;     // that slice
+        uint64_t tickets[kWindow] = {};
+        uint64_t submitted = 0, waited = 0; // slices so far
+        bool stop = false;                  // nothing more is submitted
+        bool open = false;                  // on_iteration_start fired for done_it, its on_iteration_end not yet
+        auto complete = [&](uint64_t it, bool rendered) { // iteration `it` has been finished (ptk_group_finish_iteration)
             ptk_counters counters{};
-            if (healthy && ptk_group_get_counters(group, &counters) == PTK_OK) {
+            if (rendered) healthy = ok(ptk_group_wait_iteration(group, it, reinterpret_cast<float*>(frame.data()), &counters));
+            if (!healthy) return;
+            if (rendered) {
                 self.paths_traced = counters.paths;
                 self.rays_cast = counters.rays;
             }
-            if (!healthy) break;
             self.progress = 1.0f;
             self.iteration = it;
             self.samples_per_pixel += spi;
             self.on_iteration_end(frame, it);
+            open = false;
+        };
+        if (healthy && wanted(0) && !self.is_interrupted()) {
+            self.on_iteration_start(0);
+            open = true;
+        }
+        while (healthy && open) {
+            if (spi == 0) { // traces nothing, like the reference's empty sample loop, and leaves the image as it is
+                complete(done_it, false);
+                ++done_it;
+                if (healthy && wanted(done_it) && !self.is_interrupted()) {
+                    self.on_iteration_start(done_it);
+                    open = true;
+                }
+                continue;
+            }
+            // fill the window
+            while (healthy && !stop && submitted - waited < kWindow && wanted(sub_it)) {
+                if (self.is_interrupted()) {
+                    stop = true;
+                    break;
+                }
+                healthy = ok(ptk_group_submit_slice(group, aov, seed, sub_it, spi, sub_k, K, &tickets[submitted % kWindow]));
+                if (!healthy) break;
+                ++submitted;
+                if (++sub_k == K) {
+                    healthy = ok(ptk_group_finish_iteration(group, sub_it, spi, K, K, 1));
+                    sub_k = 0;
+                    ++sub_it;
+                }
+            }
+            if (!healthy) break;
+            if (waited == submitted) {
+                // nothing in flight and nothing more to come: the open iteration ends with the slices it got
+                if (sub_it == done_it) { // (else it was finished whole and completed below)
+                    if (sub_k > 0) healthy = ok(ptk_group_finish_iteration(group, done_it, spi, sub_k, K, 1));
+                    if (healthy) complete(done_it, sub_k > 0);
+                }
+                break;
+            }
+            healthy = ok(ptk_group_wait_slice(group, tickets[waited % kWindow]));
+            if (!healthy) break;
+            ++waited;
+            ++done_k;
+            self.progress = float(done_k) / float(K);
+            if (done_k == K) {
+                complete(done_it, true);
+                done_k = 0;
+                ++done_it;
+                // the reference's loop condition (abstract_pathtracer.cpp:38).  After an interrupt the slices of later
+                // iterations that were already submitted are left to run out unreported: the frame handed to on_end is
+                // the one of the last iteration that ended.
+                if (healthy && wanted(done_it) && !self.is_interrupted()) {
+                    self.on_iteration_start(done_it);
+                    open = true;
+                }
+            }
         }
         self.on_end(frame);
         held.reset();

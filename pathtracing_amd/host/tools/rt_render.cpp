@@ -14,12 +14,16 @@
 //             [--iterations N] [--spp-per-iteration K] [--seed X] [--device D | --devices D0,D1,..]
 //             [--png-out image.png]   (what the reference CLI writes: CLI/main.cpp:85-107; needs stb_image_write.h on the include path at build time)
 //             [--threads T] [--ldr-out rgba8.bin] [--interrupt-after N] [--asset-root DIR]
+//             [--max-paths N] [--interrupt-at I F]
 //             [--aov albedo|emission|roughness|metallic|normal]   (rt::utility::debug_pathtracer instead of rt::pathtracer)
 //             [--then-camera PX PY PZ DX DY DZ --then-out image2.bin]   (a second run() on the same
 //              rt::pathtracer with only the camera moved: the Sandbox pattern, rtsb.cpp:295-299,355)
 //
 // image.bin: W*H*3 little-endian floats, row 0 = top (linear HDR, before the CLI tone map).
+#include <atomic>
+#include <chrono>
 #include <cinttypes>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -166,6 +170,12 @@ int main(int argc, char** argv)
     uint64_t iterations = 10, spi = 256, seed = 0; // CLI/main.cpp:14-17,70
     uint32_t threads = 4;
     uint64_t interrupt_after = 0; // > 0: call interrupt() from the on_iteration_end handler (Sandbox-style stop)
+    // --interrupt-at I F: a second thread polls pathtracer_result::progress the way Sandbox's GUI thread does
+    // (rtsb.cpp:264,434) and calls interrupt() once iteration I (0-based) has reached progress F: a stop inside an iteration
+    bool watch = false;
+    uint64_t watch_iteration = 0;
+    float watch_progress = 0.0f;
+    uint64_t max_paths = 0; // ray-queue capacity per launch chain (0 = library default); small values cut an iteration into many slices
     int device = 0;
     std::vector<int> devices;
     std::string scene_file, out_file = "result.bin", ldr_file, png_file, asset_root, then_out, aov;
@@ -186,6 +196,12 @@ int main(int argc, char** argv)
         else if (p == "--device" && need(1)) device = std::stoi(argv[++i]);
         else if (p == "--interrupt-after" && need(1)) interrupt_after = std::stoull(argv[++i]);
         else if (p == "--asset-root" && need(1)) asset_root = argv[++i];
+        else if (p == "--max-paths" && need(1)) max_paths = std::stoull(argv[++i]);
+        else if (p == "--interrupt-at" && need(2)) {
+            watch = true;
+            watch_iteration = std::stoull(argv[++i]);
+            watch_progress = std::strtof(argv[++i], nullptr);
+        }
         else if (p == "--aov" && need(1)) aov = argv[++i];
         else if (p == "--then-out" && need(1)) then_out = argv[++i];
         else if (p == "--devices" && need(1)) {
@@ -235,6 +251,7 @@ int main(int argc, char** argv)
     pathtracer.device.device = device;
     pathtracer.device.devices = devices;
     pathtracer.device.seed = seed;
+    pathtracer.device.max_paths_per_launch = max_paths;
     rt::view_parameters view_params;
     rt::trace_parameters trace_params;
     view_params.width = width;
@@ -259,8 +276,40 @@ int main(int argc, char** argv)
 
     auto result = tracer.run(view_params, trace_params, scene);
 
-    uint64_t starts = 0, ends = 0;
+    std::atomic<uint64_t> starts{ 0 }, ends{ 0 };
+    std::atomic<bool> finished{ false };
     result->on_iteration_start.subscribe([&starts](const uint64_t&) { ++starts; });
+    std::thread watcher;
+    if (watch)
+        watcher = std::thread([&, result] {
+            uint64_t samples = 0, at_end = 0;
+            float last = 0.0f, lo = 2.0f, hi = 0.0f, fired_at = -1.0f;
+            bool monotone = true;
+            while (!finished.load()) {
+                const uint64_t e = ends.load();
+                const float pr = result->progress.load();
+                if (ends.load() == e) { // both reads belong to the same iteration
+                    if (e != at_end) {
+                        at_end = e;
+                        last = 0.0f;
+                    }
+                    if (pr < last) monotone = false;
+                    last = pr;
+                    if (pr > 0.0f) {
+                        lo = std::min(lo, pr);
+                        hi = std::max(hi, pr);
+                    }
+                    ++samples;
+                    if (fired_at < 0.0f && e == watch_iteration && pr >= watch_progress && starts.load() > e) {
+                        result->interrupt();
+                        fired_at = pr;
+                    }
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+            std::printf("watch: samples=%" PRIu64 " monotone=%d min=%.4f max=%.4f interrupted_at_progress=%.4f\n", samples, monotone ? 1 : 0,
+                        lo, hi, fired_at);
+        });
     result->on_iteration_end.subscribe([&, result](const rt::image&, const uint64_t& iteration) {
         ++ends;
         const float elapsed = result->get_elapsed_time();
@@ -298,6 +347,8 @@ int main(int argc, char** argv)
         }
     });
     result->wait();
+    finished = true;
+    if (watcher.joinable()) watcher.join();
 
     if (!result->error().empty()) {
         std::fprintf(stderr, "rt_render: %s\n", result->error().c_str());
@@ -324,6 +375,6 @@ int main(int argc, char** argv)
     }
     std::printf("done: iteration=%" PRIu64 " spp=%" PRIu64 " paths=%" PRIu64 " rays=%" PRIu64 " events=%" PRIu64 "/%" PRIu64 "\n",
                 result->iteration.load(), result->samples_per_pixel.load(), result->paths_traced.load(),
-                result->rays_cast.load(), starts, ends);
+                result->rays_cast.load(), starts.load(), ends.load());
     return 0;
 }

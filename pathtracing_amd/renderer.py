@@ -21,6 +21,86 @@ class PtkError(RuntimeError):
         self.code = code
 
 
+class Group:
+    """Owns one ptk_group: several contexts (device ids may repeat) behind one driver (include/ptk.h, ptk_group_*)."""
+
+    def __init__(self, devices):
+        self._lib = _abi.load()
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._lib.ptk_group_create(ids, len(devices), C.byref(h))
+        if rc != _abi.PTK_OK:
+            raise PtkError(rc, self._lib.ptk_group_last_error(None).decode())
+        self._h = h
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ptk_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, allow=()):
+        if rc != _abi.PTK_OK and rc not in allow:
+            raise PtkError(rc, self._lib.ptk_group_last_error(self._h).decode())
+        return rc
+
+    def upload(self, scene):
+        desc, keep = scene.to_desc()
+        self._check(self._lib.ptk_group_scene_upload(self._h, C.byref(desc)))
+
+    def render_begin(self, width, height, fov_y=math.pi / 4.0, max_paths=0):
+        self._check(self._lib.ptk_group_render_begin(self._h, width, height, float(np.float32(fov_y)), max_paths))
+        self.width, self.height = width, height
+
+    def render_iteration(self, seed, iteration, spi):
+        """Blocking iteration; returns True if it ran to the end, False if ptk_group_request_interrupt cut it short."""
+        return self._check(self._lib.ptk_group_render_iteration(self._h, seed, iteration, spi), allow=(_abi.PTK_INTERRUPTED,)) == _abi.PTK_OK
+
+    def request_interrupt(self):
+        self._check(self._lib.ptk_group_request_interrupt(self._h))
+
+    def progress(self):
+        return float(self._lib.ptk_group_progress(self._h))
+
+    def slices(self, spi):
+        k = C.c_uint32()
+        self._check(self._lib.ptk_group_iteration_slices(self._h, spi, C.byref(k)))
+        return k.value
+
+    def submit_slice(self, seed, iteration, spi, slice_index, num_slices, aov=-1):
+        t = C.c_uint64()
+        self._check(self._lib.ptk_group_submit_slice(self._h, aov, seed, iteration, spi, slice_index, num_slices, C.byref(t)))
+        return t.value
+
+    def wait_slice(self, ticket):
+        self._check(self._lib.ptk_group_wait_slice(self._h, ticket))
+
+    def finish_iteration(self, iteration, spi, slices_done, num_slices, download=True):
+        self._check(self._lib.ptk_group_finish_iteration(self._h, iteration, spi, slices_done, num_slices, 1 if download else 0))
+
+    def wait_iteration(self, iteration, want_image=True):
+        img = np.empty((self.height, self.width, 3), np.float32) if want_image else None
+        cnt = _abi.Counters()
+        self._check(self._lib.ptk_group_wait_iteration(self._h, iteration, img.ctypes.data if want_image else None, C.byref(cnt)))
+        return img, (cnt.paths, cnt.rays)
+
+    def read_image(self):
+        img = np.empty((self.height, self.width, 3), np.float32)
+        self._check(self._lib.ptk_group_read_image(self._h, img.ctypes.data))
+        return img
+
+    def counters(self):
+        cnt = _abi.Counters()
+        self._check(self._lib.ptk_group_get_counters(self._h, C.byref(cnt)))
+        return cnt.paths, cnt.rays
+
+
 class Context:
     """Owns one ptk_ctx (one GPU, one stream)."""
 

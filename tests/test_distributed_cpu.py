@@ -60,6 +60,24 @@ def _worker(rank, world, port, spi, iterations, out_path):
     dist.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, spi, iterations, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pathtracing_amd import parallel
+    pipe = parallel.IterationPipeline(OracleBackend(), W, H, "cpu", rank, world, dist)
+    for it in range(iterations):
+        pipe.step(it, spi, seed=3)
+    pipe.synchronize()
+    if rank == 0:
+        assert pipe.reduces == iterations
+        np.save(out_path, pipe.image.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _single(spi, iterations):
     from pathtracing_amd import parallel
     be = OracleBackend()
@@ -81,3 +99,17 @@ def test_two_ranks_match_one_rank(tmp_path, spi, port):
         assert np.array_equal(two, one)          # disjoint pixels: the reduce adds zeros
     else:
         np.testing.assert_allclose(two, one, rtol=1e-6, atol=1e-6)  # only the fp32 summation order differs
+
+
+@pytest.mark.parametrize("spi,port", [(8, 29613), (1, 29614)])
+def test_pipeline_of_two_ranks_matches_one_rank(tmp_path, spi, port):
+    """parallel.IterationPipeline (bench.py's driver: double-buffered sums, exchange off the render stream) with the
+    oracle plugged in, 2 ranks over gloo, three iterations so that a sum buffer is used twice."""
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_pipeline_worker, args=(2, port, spi, 3, out), nprocs=2, join=True)
+    two = np.load(out)
+    one = _single(spi, 3)
+    if spi == 1:
+        assert np.array_equal(two, one)
+    else:
+        np.testing.assert_allclose(two, one, rtol=1e-6, atol=1e-6)

@@ -16,7 +16,7 @@ def test_abi_exports_every_declared_symbol():
     """libptk.so loads without a GPU and exports exactly what include/ptk.h declares."""
     lib = _abi.load()
     header = open(os.path.join(ROOT, "include", "ptk.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void|const char\*|ptk_ctx\*)\s+(ptk_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:int|void|void\*|float|const char\*|ptk_ctx\*)\s+(ptk_\w+)\s*\(", header, re.M))
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)

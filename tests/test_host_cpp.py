@@ -238,6 +238,46 @@ def test_rt_api_endless_run_stops_on_interrupt(tmp_path):
 
 
 @pytest.mark.gpu
+def test_rt_api_interrupt_inside_an_iteration(tmp_path):
+    """interrupt() from a second thread that polls pathtracer_result::progress like Sandbox's GUI thread (rtsb.cpp:264,434),
+    landing inside iteration 1 of a run whose iterations are 64 launch chains each (--max-paths): progress is monotone in
+    (0, 1] within an iteration (abstract_pathtracer.cpp:51), on_iteration_end and on_end still fire (:109,114), no further
+    iteration starts (:38), and the image is iteration 1's running mean on the pixels whose slices were rendered and
+    iteration 0's on the others (the reference's unfinished scan lines)."""
+    txt = tmp_path / "room.txt"
+    write_scene_text(scene_path("room"), str(txt), str(tmp_path))
+    w = h = 128
+    spi = 256
+    common = ["--scene", str(txt), "--resolution", str(w), str(h), "--spp-per-iteration", str(spi), "--seed", "8", "--max-paths", "65536"]
+    imgs = {}
+    for iters in (1, 2):
+        out_bin = tmp_path / f"full{iters}.bin"
+        out = subprocess.run([_binary("rt_render"), *common, "--out", str(out_bin), "--iterations", str(iters)],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.stdout, out.stderr)
+        imgs[iters] = np.fromfile(out_bin, dtype=np.float32).reshape(-1, 3)
+    out_bin = tmp_path / "cut.bin"
+    out = subprocess.run([_binary("rt_render"), *common, "--out", str(out_bin), "--iterations", "6", "--interrupt-at", "1", "0.3"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    lines = out.stdout.strip().splitlines()
+    watch = dict(kv.split("=") for kv in next(l for l in lines if l.startswith("watch:")).split()[1:])
+    assert watch["monotone"] == "1" and 0.0 < float(watch["min"]) <= float(watch["max"]) <= 1.0
+    assert 0.3 <= float(watch["interrupted_at_progress"]) < 1.0
+    fields = dict(kv.split("=") for kv in lines[-1].split()[1:])
+    assert int(fields["iteration"]) == 1 and int(fields["spp"]) == 2 * spi   # the partial iteration counts, as in the reference (:105-106)
+    starts, ends = (int(x) for x in fields["events"].split("/"))
+    assert ends == 2 and 1 <= starts <= 2
+    assert w * h * spi < int(fields["paths"]) < 2 * w * h * spi
+    img = np.fromfile(out_bin, dtype=np.float32).reshape(-1, 3)
+    changed = np.nonzero((img != imgs[1]).any(axis=1))[0]
+    cut = int(changed[-1]) + 1
+    assert 0.3 * w * h <= cut < w * h
+    assert np.array_equal(img[:cut], imgs[2][:cut]) and np.array_equal(img[cut:], imgs[1][cut:])
+    assert int(fields["paths"]) == w * h * spi + cut * spi
+
+
+@pytest.mark.gpu
 def test_rt_api_seed_decides_the_image(tmp_path):
     txt = tmp_path / "furnace.txt"
     write_scene_text(scene_path("furnace"), str(txt), str(tmp_path))

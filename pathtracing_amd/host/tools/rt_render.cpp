@@ -282,25 +282,32 @@ int main(int argc, char** argv)
     std::thread watcher;
     if (watch)
         watcher = std::thread([&, result] {
+            // the running iteration = iterations completed so far (samples_per_pixel is bumped once per iteration, before
+            // its on_iteration_end, abstract_pathtracer.cpp:105-109).  progress keeps the finished iteration's 1.0 until
+            // the next one reports its first slice, as the reference keeps its last scan line's value: one drop from 1.0
+            // per iteration is the restart, any other decrease is an error
             uint64_t samples = 0, at_end = 0;
             float last = 0.0f, lo = 2.0f, hi = 0.0f, fired_at = -1.0f;
-            bool monotone = true;
+            bool monotone = true, dropped = false;
             while (!finished.load()) {
-                const uint64_t e = ends.load();
+                const uint64_t e = spi ? result->samples_per_pixel.load() / spi : 0;
                 const float pr = result->progress.load();
-                if (ends.load() == e) { // both reads belong to the same iteration
+                if ((spi ? result->samples_per_pixel.load() / spi : 0) == e) { // both reads belong to the same iteration
                     if (e != at_end) {
                         at_end = e;
-                        last = 0.0f;
+                        dropped = false;
                     }
-                    if (pr < last) monotone = false;
+                    if (pr < last) {
+                        if (dropped || last != 1.0f) monotone = false;
+                        dropped = true;
+                    }
                     last = pr;
                     if (pr > 0.0f) {
                         lo = std::min(lo, pr);
                         hi = std::max(hi, pr);
                     }
                     ++samples;
-                    if (fired_at < 0.0f && e == watch_iteration && pr >= watch_progress && starts.load() > e) {
+                    if (fired_at < 0.0f && e == watch_iteration && pr >= watch_progress && pr < 1.0f) {
                         result->interrupt();
                         fired_at = pr;
                     }

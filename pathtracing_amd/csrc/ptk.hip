@@ -832,6 +832,14 @@ __global__ __launch_bounds__(kBlock) void k_tally(const uint32_t* __restrict__ s
     }
 }
 
+// small counter arrays are cleared by a kernel, not by a memset node: the launch chain must replay inside a HIP graph
+// (ptk_render_samples_noalloc_dev under capture), where a captured 40-byte memset of the static scratch did not run
+__global__ __launch_bounds__(kBlock) void k_clear_u32(uint32_t* __restrict__ p, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 // abstract_pathtracer.cpp:66,88-90
 __global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ sum_rgb, float* __restrict__ image,
                                                     uint64_t n, float spi, float t)
@@ -1561,10 +1569,10 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
             A.dense = (!split && R.state_other && R.bucket && !(kernel_mode(c, true) & 2) && !(kernel_mode(c, false) & 2)) ? 1u : 0u;
             A.state_other = R.state_other;
             A.bucket = R.bucket;
-            if (A.dense) PTK_HIP(c, hipMemsetAsync(R.bucket, 0, (PTK_MAX_DEPTH + 1) * kBuckets * sizeof(uint32_t), c->stream));
+            if (A.dense) k_clear_u32<<<dim3(((PTK_MAX_DEPTH + 1) * kBuckets + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream>>>(R.bucket, (PTK_MAX_DEPTH + 1) * kBuckets);
             const dim3 grid(A.num_segments), block(kBlock);
             if (split) {
-                PTK_HIP(c, hipMemsetAsync(R.split_counters, 0, kSplitCounters * sizeof(uint32_t), c->stream));
+                k_clear_u32<<<dim3(1), dim3(kBlock), 0, c->stream>>>(R.split_counters, kSplitCounters);
                 SplitBufs Q{};
                 Q.q[0] = R.state;
                 Q.q[1] = R.state2;

@@ -129,8 +129,9 @@ def test_room_matches_reference_png(gpu_ctx):
     (Monte-Carlo noise of the two images).  Inside that region (the back wall above the right box, a band from there
     down to the chrome ball, the floor in front of the right box, a strip of the ceiling) the PNG is 2-6 % brighter
     than this scene file renders, GPU and CPU oracle alike; no source-level variant of room.json (roughness of any
-    node through the unused r03 / r09 samplers, lamp radiance) reproduces it, so that region is excluded from the
-    tight bar and pinned at its measured level instead, so that neither side can drift unnoticed."""
+    node through the unused r03 / r09 samplers, lamp radiance) reproduces it.  PARITY WITH THIS PNG IS UNEXPLAINED,
+    NOT SHOWN: the bars below ask for closeness to 1.0 (a change that brings the image closer to the PNG passes), the
+    deviating region is reported, not pinned."""
     from PIL import Image
     import torch
     gpu_ctx.upload(get_scene("room"))
@@ -167,11 +168,12 @@ def test_room_matches_reference_png(gpu_ctx):
     dev_region[22:28, 4:5] = True           # left edge of the left box
     flat = ratio[~lamp & ~dev_region]
     assert flat.size > 600
-    assert abs(np.median(flat) - 1.0165) < 0.01, np.median(flat)
-    assert ((flat > 0.985) & (flat < 1.05)).mean() > 0.98, ((flat > 0.985) & (flat < 1.05)).mean()
-    assert flat.min() > 0.95 and flat.max() < 1.06, (flat.min(), flat.max())
+    assert abs(np.median(flat) - 1.0) < 0.03, np.median(flat)  # measured 1.0165: a constant +1.7 % nothing in the sources explains
+    assert (np.abs(flat - 1.0) < 0.05).mean() > 0.98, (np.abs(flat - 1.0) < 0.05).mean()
+    assert np.abs(flat - 1.0).max() < 0.07, (flat.min(), flat.max())
     strip = ratio[5:18, 23:27].mean()
-    assert 0.94 < strip < 0.98, strip       # measured 0.960: the unexplained deficit, pinned
+    print(f"room PNG: flat-region median ratio {np.median(flat):.4f}; back-wall strip {strip:.4f} (measured 0.960 in round 2: unexplained)")
+    assert abs(strip - 1.0) < 0.08, strip   # a sanity bound only: no side of the open question is enforced
 
 
 def test_mario_figure_matches_reference_png(gpu_ctx):

@@ -34,15 +34,55 @@ def test_noalloc_equals_allocating_entry_point(_gpu_ctx_session, name):
                                k["pixel_begin"], k["pixel_count"])
         ctx.synchronize()
         ctx.reset_counters()
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info(dev)
         ctx.render_samples_noalloc_dev(k["seed"], k["sample_begin"], k["sample_count"], out.data_ptr(), k["accumulate"],
                                        k["pixel_begin"], k["pixel_count"])
         ctx.synchronize()
+        free_after, _ = torch.cuda.mem_get_info(dev)
+        assert free_after == free_before      # the property the entry point exists for: no device allocation
         paths, rays = ctx.counters()
         assert paths == k["pixel_count"] * k["sample_count"]
         assert paths <= rays <= 5 * paths
-        assert torch.equal(ref, out)          # bit-exact: same kernels, same chunking (one chunk)
+        # bit-exact although the allocating call above cuts the first job into three launch chains of 2^16 paths and this
+        # one runs a single chain: radiance is kept per path and summed per pixel in a fixed order, whatever the chunking
+        assert torch.equal(ref, out)
     assert float(out.min()) >= 0.0 and bool(torch.isfinite(out).all())
     assert float(out.max()) > 0.0
+
+
+@pytest.mark.parametrize("name", ["room", "mario"])
+def test_noalloc_runs_under_graph_capture(name):
+    """A hipMalloc inside a capture fails the capture; the entry point is captured into a HIP graph on a torch
+    stream, replayed twice, and the sums equal the allocating entry point's."""
+    import torch
+    from pathtracing_amd import Context
+    dev = torch.device("cuda", 0)
+    w, h, spp = 64, 48, 32
+    with Context(0) as ctx:
+        ctx.upload(get_scene(name))
+        ctx.render_begin(w, h, FOV, max_paths=1 << 16)
+        ref = torch.zeros(h, w, 3, device=dev)
+        ctx.render_samples_dev(5, 0, spp, ref.data_ptr())
+        ctx.synchronize()
+        out = torch.full((h, w, 3), -1.0, device=dev)
+        s = torch.cuda.Stream(dev)
+        ctx.set_stream(s.cuda_stream)
+        # one eager call first (lazy module loading must not happen inside the capture)
+        ctx.render_samples_noalloc_dev(5, 0, spp, out.data_ptr())
+        s.synchronize()
+        out.fill_(-1.0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ctx.render_samples_noalloc_dev(5, 0, spp, out.data_ptr())
+        for _ in range(2):
+            out.fill_(-1.0)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+        ctx.set_stream(None)
 
 
 def test_noalloc_rejects_sizes_beyond_the_maximum(_gpu_ctx_session):

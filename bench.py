@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--balance", type=int, default=None, help="PTK_OPT_BALANCE override (0/1/2), for A/B runs")
     ap.add_argument("--split", type=int, default=None, help="PTK_OPT_SPLIT override (0/1/2), for A/B runs")
     ap.add_argument("--compact", type=int, default=None, help="PTK_OPT_COMPACT override (0/1/2), for A/B runs")
+    ap.add_argument("--no-timing", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 path on a box with ONE GPU: every rank uses cuda:0 and the HDR sum "
                          "buffers are reduced through host memory (not a measurement)")
@@ -224,7 +225,9 @@ def main():
     pipe.synchronize()
     torch.cuda.synchronize(dev)
     ctx.reset_counters()
-    ctx.enable_timing(True)
+    # per-launch HIP events on the launch stream for the roofline's kernel durations, on every 4th step: the events
+    # themselves cost GPU time (1 % of a Room step, 5 % of a materials step), a quarter of the steps gives the same average
+    ctx.enable_timing(0 if args.no_timing else 4)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -295,6 +298,9 @@ def main():
             out["cpu_baseline"] = None
         # dominant kernel, rank 0's launches: k_bounce<false> (bounces 1..4), or in split mode (scenes with
         # KD-trees) the walker k_walk, which runs once per bounce
+        # the events bracket the launches of every 4th step (ctx.enable_timing(4)): per-launch work = totals / all launches
+        timed_steps = (args.steps + 3) // 4
+        launch_scale = args.steps / timed_steps if timed_steps else 1.0
         n_launch, ms = timing["k_bounce<false>"]
         n0, ms0 = timing["k_bounce<true>"]
         nw, msw = timing["k_walk"]
@@ -302,7 +308,8 @@ def main():
         pmc = load_pmc_traffic(args.workload)
         if n_launch and model is not None and not nw:
             # Room / materials: the whole scene is cache resident, HBM sees the ray queue only -> VALU-bound.
-            rays_next = (rays - paths) / world / n_launch          # rays cast per k_bounce<false> launch
+            all_launches = n_launch * launch_scale
+            rays_next = (rays - paths) / world / all_launches      # rays cast per k_bounce<false> launch
             avg_ms = ms / n_launch
             tflops = model["flops_per_ray"] * rays_next / (avg_ms * 1e-3) / 1e12
             # algorithmic HBM bytes of one launch: every ray is read (52 B); a survivor is written back (52 B), a path
@@ -311,13 +318,13 @@ def main():
             paths_w = paths / world
             # rays entering bounces 2..4 are the survivors written by bounces 1..3; bounce 0's survivors (= rays of
             # bounce 1) are written by k_bounce<true>, not by this kernel
-            queue_bytes = (52.0 * rays_in + 52.0 * max(0.0, rays_in - rays_in / (PTK_DEPTH - 1)) + 12.0 * paths_w) / n_launch
+            queue_bytes = (52.0 * rays_in + 52.0 * max(0.0, rays_in - rays_in / (PTK_DEPTH - 1)) + 12.0 * paths_w) / all_launches
             gbs = queue_bytes / (avg_ms * 1e-3) / 1e9
             measured = (pmc["k_bounce<false>"] / (avg_ms * 1e-3) / 1e9) if pmc.get("k_bounce<false>") else None
             out["roofline"] = {
                 "bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
                 "kernel": "k_bounce<false>", "traffic": pmc.get("k_bounce<false>"), "traffic_source": pmc.get("source"),
-                "avg_launch_ms": avg_ms, "launches": n_launch, "rays_per_launch": rays_next,
+                "avg_launch_ms": avg_ms, "launches": all_launches, "timed_launches": n_launch, "rays_per_launch": rays_next,
                 "first_bounce_avg_ms": (ms0 / n0) if n0 else None,
                 "flops_per_ray": model["flops_per_ray"],
                 "hbm_algorithmic_bytes_per_launch": queue_bytes, "hbm_algorithmic_GBs": gbs, "hbm_measured_GBs": measured,
@@ -334,7 +341,7 @@ def main():
             # Scenes with KD-trees (Mario, config 5): one bounce = k_bounce_split (spheres, one-leaf meshes, parking) +
             # k_walk (KD-trees of the parked rays) + k_shade_parked; k_walk dominates.  SURVEY 8d: HBM-bound line from
             # the build's own pruned walk (V nodes, T triangles per ray: oracle walk model 1).
-            rays_launch = rays / world / nw
+            rays_launch = rays / world / (nw * launch_scale)
             walk_ms = msw / nw
             V, T = model["kd_nodes_per_ray"], model["triangles_per_ray"]
             touched = (64.0 * V + 64.0 * T) * rays_launch          # bytes the walk requests (mostly cache hits)

@@ -388,6 +388,9 @@ int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
  * roofline leg).  No reference counterpart (the reference only has wall-clock
  * get_elapsed_time, abstract_pathtracer.cpp:133-137).  After enable(1) every
  * kernel launch is bracketed by two events (at most 8192 launches are kept);
+ * enable(n), n > 1, brackets the launches of every n-th ptk_render_samples_dev call only
+ * (the events themselves cost GPU time: 1 % on Room's long kernels, 5 % on a chain of
+ * short ones; a sample of the calls gives the same averages);
  * ptk_get_timing synchronises, fills out[PTK_KERNEL_KINDS] and clears the log. */
 enum {
     PTK_KERNEL_BOUNCE_FIRST = 0,    /* k_bounce<true>:  generate + cast + shade, bounce 0 */

@@ -1037,7 +1037,8 @@ struct ptk_ctx {
 
     // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
     bool timing = false;
-    bool timing_hold = false; // set while the no-alloc entry point runs: HIP events are allocations
+    bool timing_hold = false; // set while the no-alloc entry point runs (HIP events are allocations) or a call is not sampled
+    uint32_t timing_every = 1, timing_tick = 0; // ptk_ctx_enable_timing(n): every n-th ptk_render_samples_dev call is timed
     struct Stamp {
         int kind;
         hipEvent_t a, b;
@@ -2355,7 +2356,11 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
     R.pend_mask = c->d_pend_mask;
     R.pend_best = c->d_pend_best;
     R.cap = cap;
+    // per-launch events cost a few microseconds of GPU pipeline each (5 % on a chain of short kernels): with
+    // ptk_ctx_enable_timing(n > 1) only every n-th call carries them
+    c->timing_hold = c->timing && (c->timing_tick++ % c->timing_every) != 0u;
     const int rc = render_samples_impl(c, R, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb, accumulate);
+    c->timing_hold = false;
     if (rc == PTK_OK && !split && c->compact == 2 && c->snapshot_ev && !c->snapshot_pending) {
         PTK_HIP(c, hipMemcpyAsync(c->h_snapshot, c->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         PTK_HIP(c, hipEventRecord(c->snapshot_ev, c->stream));
@@ -2707,6 +2712,8 @@ int ptk_ctx_enable_timing(ptk_ctx* c, int enable)
     PTK_HIP(c, hipStreamSynchronize(c->stream));
     drop_stamps(c);
     c->timing = enable != 0;
+    c->timing_every = enable > 1 ? (uint32_t)enable : 1u;
+    c->timing_tick = 0;
     return PTK_OK;
 }
 

@@ -298,7 +298,8 @@ class Context:
         self._check(self._lib.ptk_ctx_set_option(self._h, option, value))
 
     def enable_timing(self, on=True):
-        self._check(self._lib.ptk_ctx_enable_timing(self._h, 1 if on else 0))
+        """on = True / 1: every launch is bracketed by HIP events; n > 1: the launches of every n-th render_samples_dev call."""
+        self._check(self._lib.ptk_ctx_enable_timing(self._h, int(on)))
 
     def timing(self):
         """{kernel name: (launches, total_ms)} since enable_timing / the last call."""

@@ -169,7 +169,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    distributed = world > 1
+    # PTK_BENCH_FORCE_DIST=1: a one-rank job still goes through torch.distributed (rehearsal of the RCCL leg on a one-GPU
+    # box: process group, reduce on the exchange stream, barriers)
+    distributed = world > 1 or os.environ.get("PTK_BENCH_FORCE_DIST") == "1"
     if args.backend == "gloo":
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -212,7 +214,7 @@ def main():
     ctx.render_begin(W, H, FOV)
     from pathtracing_amd import parallel
     pipe = parallel.IterationPipeline(ctx, W, H, dev, rank, world, dist if distributed else None,
-                                      host_reduce=(args.backend == "gloo"))
+                                      host_reduce=(args.backend == "gloo"), force_exchange=distributed)
     # samples per pixel of one step over all ranks: weak = 256 per rank, strong = 256 in total (rank r renders the
     # r-th part of the step's global sample range either way: parallel.iteration_share)
     step_spi = SPI * world if args.scaling == "weak" else SPI

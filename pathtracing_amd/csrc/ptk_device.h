@@ -1612,6 +1612,14 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
         float dd = 0.0f;
         V3 bar = mk(0.0f, 0.0f, 0.0f), p = mk(0.0f, 0.0f, 0.0f);
         PTK_STAT(S, 18, 1);
+#ifdef PTK_STATS
+        { // how many items the two side tests of scene.cpp:149,158 alone would reject
+            const V3 v0s = mk(q0.x, q0.y, q0.z), Ns = mk(q0.w, q1.x, q1.y);
+            const bool side_out = valid && (dot(co - v0s, Ns) < 0 || dot(cd, Ns) >= 0);
+            const uint64_t so = __builtin_amdgcn_ballot_w64(side_out);
+            PTK_STAT(S, 31, __popcll(so));
+        }
+#endif
         const bool hit = valid && tri_eval(q0, q1, q2, q3, co, cd, dd, bar, p) && dd < 3.402823466e+38f;
         const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | slot;
         if (hit) atomicMin(&L.key[c], key);

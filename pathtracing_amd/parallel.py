@@ -56,11 +56,12 @@ class IterationPipeline:
 
     `backend` as for render_iteration; with CUDA tensors it must also have set_stream (pathtracing_amd.Context)."""
 
-    def __init__(self, backend, width, height, device, rank=0, world=1, dist=None, host_reduce=False):
+    def __init__(self, backend, width, height, device, rank=0, world=1, dist=None, host_reduce=False, force_exchange=False):
         import torch
         self.torch = torch
         self.backend, self.width, self.height = backend, width, height
         self.rank, self.world, self.dist, self.host_reduce = rank, world, dist, host_reduce
+        self.exchange_always = force_exchange and dist is not None  # a one-rank group still calls reduce (rehearsal)
         self.cuda = torch.device(device).type == "cuda"
         self.total = [torch.zeros(height, width, 3, dtype=torch.float32, device=device) for _ in range(2)]
         self.image = torch.zeros(height, width, 3, dtype=torch.float32, device=device)
@@ -87,7 +88,7 @@ class IterationPipeline:
                 self.backend.render_samples_dev(seed, s0, ns, total.data_ptr(), accumulate=False, pixel_begin=p0, pixel_count=np_)
 
         def exchange():
-            if self.world > 1:
+            if self.world > 1 or self.exchange_always:
                 if self.host_reduce:  # rehearsal over gloo with device tensors: through the host
                     host = total.cpu()
                     self.dist.reduce(host, dst=0, op=self.dist.ReduceOp.SUM)

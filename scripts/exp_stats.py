@@ -42,5 +42,6 @@ if v[22]:
     rays = max(1, v[24])
     print(f"walker: parked rays {v[24]} in {v[25]} refills; descend steps {v[22]} (avg lanes {v[23]/v[22]:.1f}, {v[23]/rays:.1f} per ray); "
           f"leaf stages {v[26]} (avg leaf lanes {v[27]/max(1,v[26]):.1f}), triangle items {v[28]} ({v[28]/rays:.1f} per ray) in {v[18]} iterations "
-          f"({v[28]/max(1,v[18]):.1f} per iteration); pop passes {v[29]} (avg lanes {v[30]/max(1,v[29]):.1f})")
+          f"({v[28]/max(1,v[18]):.1f} per iteration); pop passes {v[29]} (avg lanes {v[30]/max(1,v[29]):.1f}); "
+          f"items the side tests alone reject: {v[31]} ({100.0*v[31]/max(1,v[28]):.1f} %)")
 ctx.close()

@@ -347,7 +347,7 @@ int ptk_counters_download_async(ptk_ctx* ctx, ptk_counters* host_out);
  * tested in the uniform loop and each lane then visits only the nodes whose box it pierced;
  * 2 (default) = 0 for the coherent primary rays of bounce 0 (1 if PTK_OPT_NODE_CULL applies), 1 for
  * later bounces and for ptk_intersect_batch.  No reference counterpart. */
-enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5, PTK_OPT_DEVICE_KD = 6, PTK_OPT_WALK_STACK = 7, PTK_OPT_COMPACT = 8 };
+enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5, PTK_OPT_DEVICE_KD = 6, PTK_OPT_WALK_STACK = 7, PTK_OPT_COMPACT = 8, PTK_OPT_FUSE = 9 };
 /* PTK_OPT_KD_PRUNE: how a multi-node KD-tree is walked (mesh::intersect_internal,
  * scene.cpp:188-212).  0 = the reference's order, every box-hit node is visited;
  * 1 (default) = near child first (by the sign of the ray direction on the split axis),
@@ -381,7 +381,12 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * runs on full wavefronts; 2 (default) = decided per context from the rays per path of the chunks rendered so far
  * (a snapshot of the counters behind each call): below 4 rays per path (an open scene) it packs across segments,
  * otherwise in place.  The image does not depend on it (radiance is kept per path).
- * ptk_render_samples_noalloc_dev always packs in place. */
+ * ptk_render_samples_noalloc_dev always packs in place.
+ * PTK_OPT_FUSE: scenes without KD-trees, pooled work lists.  1 = the five bounces of a path run in ONE kernel that keeps the
+ * ray in registers from bounce to bounce: no ray queue traffic, no compaction, one launch per chain instead of five; a path
+ * that ends early idles its lane, so this only pays where nearly all paths live five bounces (a closed scene).  0 = a kernel
+ * per bounce; 2 (default) = 1 once the counters of the chunks rendered so far show at least 4.75 rays per path, else 0.
+ * Same image, same counters. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's
@@ -399,7 +404,8 @@ enum {
     PTK_KERNEL_INTERSECT_BATCH = 3, /* k_intersect_batch (+ its walker in split mode)     */
     PTK_KERNEL_WALK = 4,            /* k_walk: KD walks of the parked rays (split mode)   */
     PTK_KERNEL_SHADE_PARKED = 5,    /* k_shade_parked: their shading                      */
-    PTK_KERNEL_KINDS = 6
+    PTK_KERNEL_BOUNCE_FUSED = 6,    /* k_bounce_fused: generate + five casts + shading    */
+    PTK_KERNEL_KINDS = 7
 };
 typedef struct ptk_kernel_timing {
     uint64_t launches;

@@ -172,8 +172,8 @@ __device__ __forceinline__ void shade_hit(const DScene& S, const Hit& h, V3 d, f
 // pathtracer::trace_recursive for one cast (pathtracer.cpp:29-68) in throughput form: updates L, and
 // for a hit before the last bounce turns (o, d, T) into the next ray.  Returns whether the path goes
 // on; a path that ends (miss, depth 5, zero throughput) writes its radiance to sample_L[path].
-__device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, const Hit& h, V3& o, V3& d, V3& T, V3& L,
-                                          uint32_t path)
+__device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, const uint32_t bounce, const Hit& h, V3& o, V3& d,
+                                          V3& T, V3& L, uint32_t path)
 {
     bool alive = false;
     if (h.node < 0) {
@@ -183,10 +183,10 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
         // the two hemisphere draws need no memory: Philox is placed ahead of the attribute / sampler loads so that it can
         // run under their round trips
         float u1 = 0.0f, u2 = 0.0f;
-        if (A.bounce + 1 < PTK_MAX_DEPTH) {
+        if (bounce + 1 < PTK_MAX_DEPTH) {
             const uint32_t pl = path / A.samples;
             const uint32_t sm = path - pl * A.samples;
-            rng_pair(A.seed, (uint32_t)(A.pixel_begin + pl), A.sample_begin + sm, 1u + A.bounce, u1, u2);
+            rng_pair(A.seed, (uint32_t)(A.pixel_begin + pl), A.sample_begin + sm, 1u + bounce, u1, u2);
         }
         V3 n;
         float uvx, uvy, uu, vv;
@@ -200,7 +200,7 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
         const float roughness = sampler_sample(S, s_roughness, uvx, uvy).x;
         const float metallic = sampler_sample(S, s_metallic, uvx, uvy).x;
         L = mk(__builtin_fmaf(T.x, emission.x, L.x), __builtin_fmaf(T.y, emission.y, L.y), __builtin_fmaf(T.z, emission.z, L.z));
-        if (A.bounce + 1 < PTK_MAX_DEPTH) {
+        if (bounce + 1 < PTK_MAX_DEPTH) {
             // pathtracer.cpp:40-54
             const V3 hemi = hemisphere_dir(n, u1, u2);
             const V3 refl = sh_madd(n, -2.0f * sh_dot(n, d), d);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock, (MODE & 2) ? 1 : 4) void k_bounce(const DSc
             }
         } else
 #endif
-        if (on) alive = shade_ray(S, A, h, o, d, T, L, path);
+        if (on) alive = shade_ray(S, A, A.bounce, h, o, d, T, L, path);
     }
 
     PTK_STAT(S, 12, PTK_CLOCK() - kc0);
@@ -338,6 +338,48 @@ __global__ __launch_bounds__(kBlock, (MODE & 2) ? 1 : 4) void k_bounce(const DSc
         st_out[9 * cap + ws] = L.x;  st_out[10 * cap + ws] = L.y; st_out[11 * cap + ws] = L.z;
         st_out[12 * cap + ws] = __uint_as_float(path);
     }
+}
+
+// ---- closed scenes: all five bounces in one kernel ---------------------------------------------------------------
+// In a closed scene (Room: the camera looks into a box) every path lives its five bounces, so the queue between bounces
+// moves nothing around: a segment's 256 rays come back as the same 256 rays.  k_bounce_fused keeps them in registers
+// instead: it generates the primary rays, then casts and shades bounce after bounce; the ray never goes to HBM (52 B
+// written and 52 B read per ray and bounce otherwise), there is no compaction, no workgroup barrier, one launch instead of
+// five.  A path that ends early (a miss, zero throughput) writes its radiance as everywhere else and its lane idles for the
+// rest of the segment, which is why the host only picks this kernel once the counters of earlier launch chains have shown
+// nearly five rays per path (PTK_OPT_FUSE).  Rays for k_tally: wave w of segment s leaves the number of rays it cast after
+// bounce 0 in seg_count[1 + w][s] (the rows the per-bounce kernels use for their live counts).
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 4) void k_bounce_fused(const DScene S, const DView V, const BounceArgs A)
+{
+    __shared__ WaveLds wave_lds[(MODE & 8) ? kBlock / 64 : 1];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = seg * kBlock;
+    const uint32_t cnt = (A.n_paths > base) ? min((uint32_t)kBlock, A.n_paths - base) : 0u;
+    WaveLds* const lds = &wave_lds[(MODE & 8) ? tid >> 6 : 0];
+    uint32_t rays = 0u; // casts of this wave after bounce 0 (wave-uniform)
+    if ((tid & ~63u) < cnt) { // the wave has a path
+        bool on = tid < cnt;
+        const uint32_t path = base + tid;
+        V3 o, d, T = mk(1.0f, 1.0f, 1.0f), L = mk(0.0f, 0.0f, 0.0f);
+        primary_ray(S, V, A, on ? path : base, o, d);
+        {
+            Hit h;
+            intersect_scene_mode<MODE, true>(S, o, d, on, h, lds);
+            if (on) on = shade_ray(S, A, 0u, h, o, d, T, L, path);
+        }
+#pragma unroll 1
+        for (uint32_t b = 1u; b < PTK_MAX_DEPTH; ++b) {
+            const uint64_t live = __builtin_amdgcn_ballot_w64(on);
+            if (live == 0ull) break;
+            rays += (uint32_t)__popcll(live);
+            Hit h;
+            intersect_scene_mode<MODE, false>(S, o, d, on, h, lds);
+            if (on) on = shade_ray(S, A, b, h, o, d, T, L, path);
+        }
+    }
+    if ((tid & 63u) == 0u) A.seg_count[(size_t)(1u + (tid >> 6)) * A.num_segments + seg] = rays;
 }
 
 // ---- split mode: scenes with KD-trees -------------------------------------------------------
@@ -465,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_split(const DScene S, const D
     // bounce 0 has no input queue: the walker reads the generated ray from queue 0
     if (FIRST && parked) queue_store(Q.q[0], cap, slot, o, d, T, L, path);
     bool alive = false;
-    if (on && !parked) alive = shade_ray(S, A, h, o, d, T, L, path);
+    if (on && !parked) alive = shade_ray(S, A, A.bounce, h, o, d, T, L, path);
 
     // parked rays and survivors are packed inside the segment (no global atomics, as in k_bounce)
     uint32_t park_rank, alive_rank, park_off, park_total, alive_off, alive_total;
@@ -745,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_parked(const DScene S, const B
     V3 L = mk(qin[9 * cap + slot], qin[10 * cap + slot], qin[11 * cap + slot]);
     const uint32_t path = __float_as_uint(qin[12 * cap + slot]);
     bool alive = false;
-    if (on) alive = shade_ray(S, A, h, o, d, T, L, path);
+    if (on) alive = shade_ray(S, A, A.bounce, h, o, d, T, L, path);
     if (last) return;
     uint32_t rank, off, total;
     block_rank_fill(alive, alive_count, rank);
@@ -1015,6 +1057,7 @@ struct ptk_ctx {
     int device_kd = 2; // PTK_OPT_DEVICE_KD
     int walk_stack = 64; // PTK_OPT_WALK_STACK (clamped to the kernels' own capacity)
     int compact = 2;     // PTK_OPT_COMPACT
+    int fuse = 2;        // PTK_OPT_FUSE
     int exp_stage = 0;   // PTK_EXP builds: stage limit of bounce 2 (environment PTK_EXP_STAGE)
     uint32_t num_trees = 0; // nodes of class kClassTree
 
@@ -1487,6 +1530,7 @@ struct RenderBufs {
     float* pend_best;             // 9 arrays of `cap` floats
     float* state_other;           // PTK_OPT_COMPACT across segments: second queue (null = compact inside the segment)
     uint32_t* bucket;             //   and its bucket counters
+    bool fused;                   // PTK_OPT_FUSE: all bounces in one kernel (k_bounce_fused), no queue
     uint64_t cap;
 };
 
@@ -1628,6 +1672,24 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
         else k_bounce<F, M><<<grid, block, 0, c->stream>>>(c->S, c->V, A);      \
     } while (0)
 #endif
+            if (R.fused && !A.dense && kernel_mode(c, true) == 8 && kernel_mode(c, false) == 8) {
+                {
+                    LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FUSED);
+                    k_bounce_fused<8><<<grid, block, 0, c->stream>>>(c->S, c->V, A);
+                }
+                const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
+                {
+                    LaunchTimer lt(c, PTK_KERNEL_ACCUMULATE);
+                    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kBlock), 0, c->stream, R.sample_L, cap,
+                                       (uint32_t)np, ns, pixel_begin + p0, sum_rgb, acc);
+                }
+                const uint32_t entries = A.num_segments * (PTK_MAX_DEPTH - 1);
+                const uint32_t tally_blocks = entries / (kBlock * 8) + 1 > 256u ? 256u : entries / (kBlock * 8) + 1;
+                hipLaunchKernelGGL(k_tally, dim3(tally_blocks), dim3(kBlock), 0, c->stream,
+                                   R.seg_count + A.num_segments, entries, (uint32_t)n_paths, c->d_counters);
+                PTK_HIP(c, hipGetLastError());
+                continue;
+            }
             {
                 LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FIRST);
                 switch (kernel_mode(c, true)) {
@@ -2346,6 +2408,8 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
     RenderBufs R{};
     R.state_other = dense ? c->d_state_other : nullptr;
     R.bucket = dense ? c->d_bucket : nullptr;
+    // PTK_OPT_FUSE: a closed scene (nearly five rays per path in the chunks rendered so far) keeps its rays in registers
+    R.fused = !split && !dense && (c->fuse == 1 || (c->fuse == 2 && c->rays_per_path >= 4.75));
     R.state = c->d_state;
     R.state2 = c->d_state2;
     R.sample_L = c->d_sample_L;
@@ -2361,7 +2425,7 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
     c->timing_hold = c->timing && (c->timing_tick++ % c->timing_every) != 0u;
     const int rc = render_samples_impl(c, R, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb, accumulate);
     c->timing_hold = false;
-    if (rc == PTK_OK && !split && c->compact == 2 && c->snapshot_ev && !c->snapshot_pending) {
+    if (rc == PTK_OK && !split && (c->compact == 2 || c->fuse == 2) && c->snapshot_ev && !c->snapshot_pending) {
         PTK_HIP(c, hipMemcpyAsync(c->h_snapshot, c->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         PTK_HIP(c, hipEventRecord(c->snapshot_ev, c->stream));
         c->snapshot_pending = true;
@@ -2672,6 +2736,10 @@ int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
     }
     if (option == PTK_OPT_COMPACT && value >= 0 && value <= 2) {
         c->compact = value;
+        return PTK_OK;
+    }
+    if (option == PTK_OPT_FUSE && value >= 0 && value <= 2) {
+        c->fuse = value;
         return PTK_OK;
     }
     if (option == PTK_OPT_KD_PRUNE && (value == 0 || value == 1)) {

@@ -365,3 +365,36 @@ def test_compaction_across_segments_changes_nothing(gpu_ctx, name):
     three = gpu_ctx.render_image(seed=11, iterations=3, spi=spp)
     gpu_ctx.set_option(_abi.PTK_OPT_COMPACT, 2)
     assert np.array_equal(out[(2, 0)][0], three)
+
+
+@pytest.mark.parametrize("name", ["room", "materials", "furnace"])
+def test_fused_bounces_change_nothing(_gpu_ctx_session, name):
+    """PTK_OPT_FUSE: the five bounces of a path in one kernel with the ray kept in registers (1) or a kernel per bounce
+    through the ray queue (0): the same arithmetic per path in the same order, radiance kept per path and summed per pixel
+    in a fixed order, so images and path / ray counters are bit-identical.  Several chunks and a ragged last segment
+    included; an open scene (paths that end early idle their lanes) as well as the closed Room the kernel is meant for.
+    Auto (2) starts unfused and switches once the counters of earlier calls have arrived: same image again."""
+    from pathtracing_amd import _abi
+    ctx = _gpu_ctx_session
+    for opt, val in ((_abi.PTK_OPT_TRAVERSAL, 2), (_abi.PTK_OPT_KD_PRUNE, 1), (_abi.PTK_OPT_NODE_CULL, 2), (_abi.PTK_OPT_BALANCE, 1),
+                     (_abi.PTK_OPT_SPLIT, 2), (_abi.PTK_OPT_COMPACT, 0)):
+        ctx.set_option(opt, val)
+    ctx.upload(get_scene(name))
+    w, h, spp = 53, 31, 24
+    out = {}
+    try:
+        for fuse, max_paths, iters in ((0, 0, 1), (1, 0, 1), (1, 5000, 1), (0, 0, 4), (2, 0, 4)):
+            ctx.set_option(_abi.PTK_OPT_FUSE, fuse)
+            ctx.render_begin(w, h, FOV, max_paths=max_paths)
+            ctx.reset_counters()
+            out[(fuse, max_paths, iters)] = (ctx.render_image(seed=11, iterations=iters, spi=spp), ctx.counters())
+    finally:
+        ctx.set_option(_abi.PTK_OPT_FUSE, 2)
+        ctx.set_option(_abi.PTK_OPT_COMPACT, 2)
+        ctx.set_option(_abi.PTK_OPT_BALANCE, 2)
+    ref_img, ref_counts = out[(0, 0, 1)]
+    assert ref_counts[0] == w * h * spp and ref_counts[1] >= ref_counts[0]
+    for key in ((1, 0, 1), (1, 5000, 1)):
+        assert np.array_equal(out[key][0], ref_img), key
+        assert out[key][1] == ref_counts, key
+    assert np.array_equal(out[(2, 0, 4)][0], out[(0, 0, 4)][0]) and out[(2, 0, 4)][1] == out[(0, 0, 4)][1]

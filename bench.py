@@ -310,8 +310,36 @@ def main():
         n0, ms0 = timing["k_bounce<true>"]
         nw, msw = timing["k_walk"]
         nsp, mssp = timing["k_shade_parked"]
+        nf, msf = timing["k_bounce_fused"]
         pmc = load_pmc_traffic(args.workload)
-        if n_launch and model is not None and not nw:
+        if nf and msf >= ms and model is not None and not nw:
+            # A closed scene (Room): all five bounces of a chain run in k_bounce_fused with the rays in registers.  The scene
+            # tables (a few KB) are cache resident and there is no ray queue: HBM sees 12 B of radiance per path -> VALU-bound.
+            all_launches = nf * launch_scale
+            chains = (nf + n0) * launch_scale                      # launch chains in the timed region (fused or not), equal in size
+            rays_launch = rays / world / chains                    # rays a chain casts = rays per k_bounce_fused launch
+            avg_ms = msf / nf
+            tflops = model["flops_per_ray"] * rays_launch / (avg_ms * 1e-3) / 1e12
+            hbm_bytes = 12.0 * (paths / world) / chains
+            traffic = pmc.get("k_bounce_fused")
+            out["roofline"] = {
+                "bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
+                "kernel": "k_bounce_fused", "traffic": traffic, "traffic_source": pmc.get("source"),
+                "avg_launch_ms": avg_ms, "launches": all_launches, "timed_launches": nf, "rays_per_launch": rays_launch,
+                "flops_per_ray": model["flops_per_ray"],
+                "hbm_algorithmic_bytes_per_launch": hbm_bytes, "hbm_algorithmic_GBs": hbm_bytes / (avg_ms * 1e-3) / 1e9,
+                "hbm_measured_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                "hbm_measured_frac": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None, "hbm_peak_GBs": PEAK_HBM_GBS,
+                "unfused_launches_in_timed_region": n_launch * launch_scale,
+                "note": ("no MFMA on this path (nothing is a dense contraction).  k_bounce_fused generates the primary rays and runs all "
+                         "five casts and shadings of a path with the ray in registers: the scene tables (a few KB) are cache resident and "
+                         "the only HBM traffic is the 12 B of radiance a path writes when it ends (hbm_algorithmic_*), so the kernel is "
+                         "bound by VALU issue.  peak = fp32 vector peak with packed FMA; hit arithmetic is built unfused "
+                         "(-ffp-contract=off, bit-exact ids), so 78.6 T op/s is the reachable ceiling.  flops = the REFERENCE's "
+                         "operation count per ray (it tests every node; tests/golden/flop_costs.json x the oracle's counts); the "
+                         "kernel's conservative cull skips most of that work, valu_busy_frac is in profiles/*_pmc.json"),
+            }
+        elif n_launch and model is not None and not nw:
             # Room / materials: the whole scene is cache resident, HBM sees the ray queue only -> VALU-bound.
             all_launches = n_launch * launch_scale
             rays_next = (rays - paths) / world / all_launches      # rays cast per k_bounce<false> launch

@@ -733,7 +733,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             if (2u * n_node >= n_leaf && 2u * n_node >= 3u * n_pop) {
                 PTK_STAT(S, 22, 1);
                 PTK_STAT(S, 23, n_node);
+#ifdef PTK_WALK_INLINE_POP
+                if (at_node) walk_descend_step<false>(W, S, stack, stack_cap);
+#else
                 if (at_node) walk_descend_step<true>(W, S, stack, stack_cap);
+#endif
             } else if (3u * n_pop >= n_leaf) {
                 PTK_STAT(S, 29, 1);
                 PTK_STAT(S, 30, n_pop);
@@ -744,7 +748,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
                 walk_leaf_stage(W, S, at_leaf, my_lds);
                 if (at_leaf && W.leaf_done >= (W.cb & kKdCountMask)) {
                     W.leaf_done = 0u;
+#if defined(PTK_WALK_INLINE_POP) && PTK_WALK_INLINE_POP >= 2
+                    walk_pop(W, stack);
+#else
                     W.cur = kWalkPop;
+#endif
                 }
             }
         }

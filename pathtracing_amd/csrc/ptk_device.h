@@ -490,12 +490,15 @@ constexpr uint32_t kWalkPop = 0xFFFFFFFEu; // walker kernel only: the lane waits
 struct KdWalk {
     const DKdNode* kd;     // the mesh's first node
     uint32_t leaf_base;    // DMesh::leaf_base
-    V3 o, d, inv;          // local ray, approximate reciprocal direction (pruning only)
+    V3 o, d, inv;          // local ray, approximate reciprocal direction
     float oabs;
-    uint32_t neg;          // bits 0-2: sign bits of d; bit 3: a stackless sweep is under way (next node in cr, end in cs)
+    uint32_t neg;          // bits 0-2: sign bits of d; bit 3: a stackless sweep is under way (next node in cr, end in cs);
+                           // bit 4: the ray's box tests always take the exact path (a zero, denormal or non-finite component)
     uint32_t cur, ca, cb, cr; // node being processed (kWalkNone = walk finished) and its header words
     float cs;
-    float T1, T2, T3, T4, T5, T6; // its six slab quotients
+    // The node's cut box as per-axis entry / exit distances along the ray: e = min, x = max of the two plane quotients of
+    // the axis, computed as (plane - o) * rcp(d) (see slab_certified).
+    float ex, xx, ey, xy, ez, xz;
     int sp;
     uint32_t leaf_done;    // triangles of the current leaf already tested (walker kernel's pooled leaf stage)
     float best_d;
@@ -503,8 +506,27 @@ struct KdWalk {
     bool found;
     V3 bar, p;
 };
+constexpr uint32_t kWalkExact = 16u; // KdWalk::neg bit: no approximate box decisions for this ray
 
-// (re)starts at node `idx`: header words + quotients from its own cut box
+// bounding_box::intersect (scene.cpp:58-75) decided from approximate quotients, when that is certain: the walker's form of
+// box_intersect_fast above.  t7 = the largest entry distance, t8 = the smallest exit distance of the box, both built from
+// quotients q = (plane - o) * rcp(d), each within eps |q| of the IEEE quotient q* the reference divides out, eps < 2^-21
+// (same subtraction, then a 1-ulp reciprocal and a product instead of a correctly rounded divide).  The maximum of such
+// values is within eps |t7| of the reference's t7*: t7* >= e*[a0] >= t7 - eps |t7| for the axis a0 that gives t7, and every
+// e*[a] <= e[a] + eps |e[a]| <= t7 + eps |t7| (for e[a] >= 0 because e[a] <= t7; for e[a] < 0 because then e[a] (1 - eps) is
+// below t7 (1 - eps) or below 0 <= t7); likewise t8.  The reference enters the box iff t8* >= 0, t7* <= t8* and t7* != -1.
+// Entry and exit of ONE axis can never cross in either arithmetic (division and multiplication are monotone), so the
+// decision is certain when t8 - t7, t8 and t7 + 1 clear delta = 5e-7 max(|t7|, |t8|) + 1e-30; anything else (a ray within a
+// relative 1e-6 of a box edge or corner, an exit at t = 0, an entry at t = -1, a flat box, non-finite values) goes to the
+// exact test.  Rays with a zero, denormal or non-finite component never come here (kWalkExact).
+__device__ __forceinline__ bool slab_certified(float t7, float t8, bool& certain)
+{
+    const float delta = __builtin_fmaf(5e-7f, fmaxf(fabsf(t7), fabsf(t8)), 1e-30f);
+    certain = (fabsf(t8 - t7) > 2.0f * delta) && (fabsf(t8) > delta) && (fabsf(t7 + 1.0f) > delta); // false on NaN / inf
+    return t7 <= t8 && t8 >= 0.0f;
+}
+
+// (re)starts at node `idx`: header words + entry / exit distances from its own cut box
 __device__ __forceinline__ void walk_enter(KdWalk& W, uint32_t idx)
 {
     const float4* __restrict__ q = reinterpret_cast<const float4*>(W.kd + idx);
@@ -514,12 +536,12 @@ __device__ __forceinline__ void walk_enter(KdWalk& W, uint32_t idx)
     W.cb = __float_as_uint(h.y);
     W.cr = __float_as_uint(h.z);
     W.cs = h.w;
-    W.T1 = (x.x - W.o.x) / W.d.x;
-    W.T2 = (x.w - W.o.x) / W.d.x;
-    W.T3 = (x.y - W.o.y) / W.d.y;
-    W.T4 = (y.x - W.o.y) / W.d.y;
-    W.T5 = (x.z - W.o.z) / W.d.z;
-    W.T6 = (y.y - W.o.z) / W.d.z;
+    const float q1 = (x.x - W.o.x) * W.inv.x, q2 = (x.w - W.o.x) * W.inv.x;
+    const float q3 = (x.y - W.o.y) * W.inv.y, q4 = (y.x - W.o.y) * W.inv.y;
+    const float q5 = (x.z - W.o.z) * W.inv.z, q6 = (y.y - W.o.z) * W.inv.z;
+    W.ex = fminf(q1, q2); W.xx = fmaxf(q1, q2);
+    W.ey = fminf(q3, q4); W.xy = fmaxf(q3, q4);
+    W.ez = fminf(q5, q6); W.xz = fmaxf(q5, q6);
 }
 
 constexpr uint32_t kWalkSweep = 8u; // KdWalk::neg bit: stackless sweep
@@ -576,7 +598,11 @@ __device__ __forceinline__ void walk_begin(KdWalk& W, const DScene& S, const DMe
     W.cur = kWalkNone;
     W.ca = W.cb = W.cr = 0u;
     W.cs = 0.0f;
-    W.T1 = W.T2 = W.T3 = W.T4 = W.T5 = W.T6 = 0.0f;
+    W.ex = W.xx = W.ey = W.xy = W.ez = W.xz = 0.0f;
+    // rays the approximate quotients say nothing reliable about: a zero / denormal direction component (rcp = inf), any
+    // non-finite or absurdly large coordinate
+    const float mag = (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + (fabsf(W.inv.x) + fabsf(W.inv.y) + fabsf(W.inv.z));
+    if (!(mag < 1e30f)) W.neg |= kWalkExact; // also on NaN
     W.sp = 0;
     W.leaf_done = 0u;
     W.best_d = 3.402823466e+38f;
@@ -586,9 +612,12 @@ __device__ __forceinline__ void walk_begin(KdWalk& W, const DScene& S, const DMe
     if (work) {
         walk_enter(W, 0u);
         const float4* __restrict__ q = reinterpret_cast<const float4*>(W.kd);
+        const float4 bx = q[1], by = q[2];
+        bool certain;
+        bool enter = slab_certified(fmaxf(fmaxf(W.ex, W.ey), W.ez), fminf(fminf(W.xx, W.xy), W.xz), certain);
+        if (!certain || (W.neg & kWalkExact)) enter = box_intersect(bx.x, bx.y, bx.z, bx.w, by.x, by.y, o, d); // scene.cpp:190 as written
         float bound;
-        if (!slab_decide(W.T1, W.T2, W.T3, W.T4, W.T5, W.T6) || kd_prune(q[2], q[3], o, W.inv, W.oabs, W.best_d, bound))
-            W.cur = kWalkNone;
+        if (!enter || kd_prune(q[2], q[3], o, W.inv, W.oabs, W.best_d, bound)) W.cur = kWalkNone;
     }
 }
 
@@ -611,17 +640,48 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
     const float4* __restrict__ qr = reinterpret_cast<const float4*>(kd + ri);
     const float4 lh = ql[0], ly = ql[2], lz = ql[3];
     const float4 rh = qr[0], ry = qr[2], rz = qr[3];
-    // the one new plane: both children's boxes are this node's box cut at `cs` on axis k
+    // the one new plane: both children's boxes are this node's box cut at `cs` on axis k.  Seen along the ray, the left
+    // child (its max plane moved to the cut) ends earlier on that axis when the ray runs upwards and starts later when it
+    // runs downwards; the right child (min plane moved) the other way round.  The other two axes are shared.
     const uint32_t k = cb >> 30;
     const float ok = k == 0u ? o.x : (k == 1u ? o.y : o.z);
-    const float dk = k == 0u ? d.x : (k == 1u ? d.y : d.z);
-    const float ts = (W.cs - ok) / dk;
-    const float T1 = W.T1, T2 = W.T2, T3 = W.T3, T4 = W.T4, T5 = W.T5, T6 = W.T6;
-    const float L2 = k == 0u ? ts : T2, L4 = k == 1u ? ts : T4, L6 = k == 2u ? ts : T6; // left: max plane moved
-    const float R1 = k == 0u ? ts : T1, R3 = k == 1u ? ts : T3, R5 = k == 2u ? ts : T5; // right: min plane moved
+    // (a select between fields of W is turned into an indexed load, which pushes the whole walk state into scratch memory:
+    // the empty asm hides where the three values come from)
+    float ix = W.inv.x, iy = W.inv.y, iz = W.inv.z;
+    asm volatile("" : "+v"(ix), "+v"(iy), "+v"(iz));
+    const float ik = k == 0u ? ix : (k == 1u ? iy : iz);
+    const float ts = (W.cs - ok) * ik;
+    const bool down = ((W.neg >> k) & 1u) != 0u; // d[k] < 0
+    // (every select below picks between computed values)
+    const float ex = W.ex, ey = W.ey, ez = W.ez, xx = W.xx, xy = W.xy, xz = W.xz;
+    const float e_yz = fmaxf(ey, ez), e_xz = fmaxf(ex, ez), e_xy = fmaxf(ex, ey);
+    const float x_yz = fminf(xy, xz), x_xz = fminf(xx, xz), x_xy = fminf(xx, xy);
+    const float e12 = k == 0u ? e_yz : (k == 1u ? e_xz : e_xy); // entry / exit of the two other axes together
+    const float x12 = k == 0u ? x_yz : (k == 1u ? x_xz : x_xy);
+    const float e_all = fmaxf(e_yz, ex), x_all = fminf(x_yz, xx); // the node's own box
+    // one child has its ENTRY on axis k moved to the cut, the other its EXIT
+    const float a7 = fmaxf(e12, ts), a8 = x_all; // entry moved
+    const float b7 = e_all, b8 = fminf(x12, ts); // exit moved
+    bool ca_, cb_;
+    const bool a_in = slab_certified(a7, a8, ca_);
+    const bool b_in = slab_certified(b7, b8, cb_);
+    bool bl_in = down ? a_in : b_in, br_in = down ? b_in : a_in;
+    const bool cl = down ? ca_ : cb_, cr_ = down ? cb_ : ca_;
+    const bool exact_only = (W.neg & kWalkExact) != 0u;
+    const bool redo_l = has_l && (!cl || exact_only), redo_r = has_r && (!cr_ || exact_only);
+    if (__builtin_amdgcn_ballot_w64(redo_l || redo_r) != 0ull) { // rare: the reference's own six divides on the child's own box
+        if (redo_l) {
+            const float4 lx = ql[1];
+            bl_in = box_intersect(lx.x, lx.y, lx.z, lx.w, ly.x, ly.y, o, d);
+        }
+        if (redo_r) {
+            const float4 rx = qr[1];
+            br_in = box_intersect(rx.x, rx.y, rx.z, rx.w, ry.x, ry.y, o, d);
+        }
+    }
     float bl, br;
-    const bool el = has_l && slab_decide(T1, L2, T3, L4, T5, L6) && !kd_prune(ly, lz, o, W.inv, W.oabs, W.best_d, bl);
-    const bool er = has_r && slab_decide(R1, T2, R3, T4, R5, T6) && !kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
+    const bool el = has_l && bl_in && !kd_prune(ly, lz, o, W.inv, W.oabs, W.best_d, bl);
+    const bool er = has_r && br_in && !kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
     const bool right_first = ((W.neg >> k) & 1u) != 0u;
     const bool take_r = er && (right_first || !el);
     if (el && er && W.sp >= cap) {
@@ -643,9 +703,10 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
         W.cb = __float_as_uint(take_r ? rh.y : lh.y);
         W.cr = __float_as_uint(take_r ? rh.z : lh.z);
         W.cs = take_r ? rh.w : lh.w;
-        W.T1 = take_r ? R1 : T1; W.T2 = take_r ? T2 : L2;
-        W.T3 = take_r ? R3 : T3; W.T4 = take_r ? T4 : L4;
-        W.T5 = take_r ? R5 : T5; W.T6 = take_r ? T6 : L6;
+        const bool entry_moved = take_r != down; // the child taken: left has its entry moved when the ray runs down, right when up
+        W.ex = (k == 0u && entry_moved) ? ts : ex; W.xx = (k == 0u && !entry_moved) ? ts : xx;
+        W.ey = (k == 1u && entry_moved) ? ts : ey; W.xy = (k == 1u && !entry_moved) ? ts : xy;
+        W.ez = (k == 2u && entry_moved) ? ts : ez; W.xz = (k == 2u && !entry_moved) ? ts : xz;
     } else if (DEFER_POP) {
         W.cur = kWalkPop;
     } else {

@@ -2078,6 +2078,31 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
             culls[i] = make_cull_record(n, d, cond, nullptr);
         }
     }
+    // The cull loop's margins, applied once: every ray that starts inside the scene's boxes (all rays after bounce 0: they
+    // start a hair off a surface) has |o|_1 <= o1max, so its margin is at most cull_k * o1max + cull_c; the table holds the
+    // boxes grown by that, rounded outwards.  Rays from further out are exempted from the per-ray cull in the kernel.
+    double o1max = 0.0;
+    for (uint32_t i = 0; i < sc->num_nodes; ++i) {
+        double s1 = 0.0;
+        bool finite = true;
+        for (int a = 0; a < 3; ++a) {
+            const double lo = nodes[i].wmin[a], hi = nodes[i].wmax[a];
+            finite = finite && std::fabs(lo) < 1e30 && std::fabs(hi) < 1e30;
+            s1 += std::fmax(std::fabs(lo), std::fabs(hi));
+        }
+        if (finite) o1max = std::fmax(o1max, s1);
+    }
+    o1max = o1max * 1.001 + 0.01; // the ray's start offset (pathtracer.h:19) and then some
+    for (uint32_t i = 0; i < sc->num_nodes; ++i) {
+        DCull& cu = culls[i];
+        float* box[3] = { cu.bx, cu.by, cu.bz };
+        const double m = (double)cu.cull_k * o1max + (double)cu.cull_c;
+        for (int a = 0; a < 3; ++a) {
+            if (!(std::fabs((double)box[a][0]) < 1e30) || !(std::fabs((double)box[a][1]) < 1e30)) continue; // switched off: stays infinite
+            box[a][0] = std::nextafter((float)((double)box[a][0] - m), -3.402823466e+38f);
+            box[a][1] = std::nextafter((float)((double)box[a][1] + m), 3.402823466e+38f);
+        }
+    }
     std::vector<DLeaf> leaf_info(sc->num_nodes);
     for (uint32_t i = 0; i < sc->num_nodes; ++i) {
         DLeaf& lf = leaf_info[i];
@@ -2181,6 +2206,7 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
     S.cam_y = sc->camera.position[1];
     S.cam_z = sc->camera.position[2];
     S.walk_stack = (uint32_t)c->walk_stack;
+    S.cull_o1max = (float)o1max;
 #ifdef PTK_STATS
     {
         void* sp = nullptr;

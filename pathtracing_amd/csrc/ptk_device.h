@@ -39,7 +39,9 @@ struct alignas(16) DNode {
 // (fn, unit length; zero if the node has none) and the cosine from which a ray direction is
 // certain to face every triangle of the node from behind (ftau; 2 = never).
 struct alignas(16) DCull {
-    float bx[2], by[2], bz[2]; // { wmin, wmax } per axis: one packed operand each
+    // { wmin - m, wmax + m } per axis, one packed operand each: the node's world box with the margin of a ray whose origin has
+    // |o|_1 <= DScene::cull_o1max already applied, m = cull_k * cull_o1max + cull_c (rays further out are never culled)
+    float bx[2], by[2], bz[2];
     float cull_k, cull_c;
     float fn[3], ftau;
     uint32_t cls;
@@ -134,6 +136,7 @@ struct DScene {
     uint32_t bg_texture, bg_mode;
     float cam_x, cam_y, cam_z;
     uint32_t walk_stack; // pending far children a KD walk may hold before it sweeps a subtree without a stack (PTK_OPT_WALK_STACK)
+    float cull_o1max;    // the |o|_1 the margins in DCull::bx.. were built for (every point of the scene's boxes, with slack)
 #ifdef PTK_STATS
     unsigned long long* stats; // experiment builds only: work counters of the balanced traversal
 #endif
@@ -1451,7 +1454,9 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
     const V3 noi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     const float o1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
     const bool sane = o1 + (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)) < 1e8f; // false on NaN
-    const float lane_bias = !lane_on ? -__builtin_inff() : sane ? 0.0f : __builtin_inff();
+    // (a ray that starts further out than the margins in the table allow for, e.g. at a camera far from the scene, is not
+    // culled per ray either; the bundle test below, which builds its own margin, still applies to it)
+    const float lane_bias = !lane_on ? -__builtin_inff() : (sane && o1 <= S.cull_o1max) ? 0.0f : __builtin_inff();
     // Bundle pre-cull (BUNDLE): one test per node for the whole wave, 64 nodes at a time, lane = node.
     // Take the first live lane's ray (oc, dc) as the central ray and let eo = max |o_i - oc|_1,
     // ed = max |d_i - dc|_1 over the wave.  A ray i that reaches a point p of a node's padded world box
@@ -1558,11 +1563,9 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
             // kernel writes other global memory (ray state) in between
             const __attribute__((address_space(4))) DCull* cu =
                 (const __attribute__((address_space(4))) DCull*)(S.cull + n);
-            const float m = __builtin_fmaf(cu->cull_k, o1, cu->cull_c);
-            const f2 pm = f2{ -m, m };
-            const f2 tx = __builtin_elementwise_fma(f2{ cu->bx[0], cu->bx[1] } + pm, f2{ inv.x, inv.x }, f2{ noi.x, noi.x });
-            const f2 ty = __builtin_elementwise_fma(f2{ cu->by[0], cu->by[1] } + pm, f2{ inv.y, inv.y }, f2{ noi.y, noi.y });
-            const f2 tz = __builtin_elementwise_fma(f2{ cu->bz[0], cu->bz[1] } + pm, f2{ inv.z, inv.z }, f2{ noi.z, noi.z });
+            const f2 tx = __builtin_elementwise_fma(f2{ cu->bx[0], cu->bx[1] }, f2{ inv.x, inv.x }, f2{ noi.x, noi.x });
+            const f2 ty = __builtin_elementwise_fma(f2{ cu->by[0], cu->by[1] }, f2{ inv.y, inv.y }, f2{ noi.y, noi.y });
+            const f2 tz = __builtin_elementwise_fma(f2{ cu->bz[0], cu->bz[1] }, f2{ inv.z, inv.z }, f2{ noi.z, noi.z });
             const float t_in = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
             const float t_out = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
             // the three reasons to drop a node as slacks that are negative when they apply: missed

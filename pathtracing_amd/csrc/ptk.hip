@@ -1085,6 +1085,7 @@ struct ptk_ctx {
     float* d_bpend_best = nullptr;
     uint64_t bsplit_cap = 0;
     bool deep_kd = false; // some mesh has more than one KD node (the pruned walk only pays off then)
+    bool all_balls = false; // every node is a sphere whose record carries its bounding ball (kernel MODE bit 4)
 
     // optional per-kernel HIP-event timing (ptk_ctx_enable_timing)
     bool timing = false;
@@ -1498,7 +1499,8 @@ int kernel_mode(const ptk_ctx* c, bool primary)
     const bool cull = c->node_cull == 1 || (c->node_cull == 2 && c->S.num_nodes >= kCullMinNodes);
     // PTK_OPT_TRAVERSAL = 2: primary rays walk every node together unless the cull pays off
     const bool lists = c->traversal == 1 || (c->traversal == 2 && (!primary || cull));
-    return (lists ? 1 : 0) | ((c->kd_prune && c->deep_kd) ? 2 : 0) | ((lists && cull) ? 4 : 0);
+    const int mode = (lists ? 1 : 0) | ((c->kd_prune && c->deep_kd) ? 2 : 0) | ((lists && cull) ? 4 : 0);
+    return (mode == 5 && c->all_balls) ? 21 : mode; // candidate lists of a spheres-only scene: culled against the bounding balls
 }
 
 // PTK_OPT_SPLIT: the two-kernel bounce (k_bounce_split + k_walk) needs the pruned walk and a tree mask of 64 bits
@@ -1706,6 +1708,7 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
                 case 2: PTK_BOUNCE(true, 2); break;
                 case 3: PTK_BOUNCE(true, 3); break;
                 case 5: PTK_BOUNCE_D(true, 5); break;
+                case 21: PTK_BOUNCE_D(true, 21); break;
                 case 7: PTK_BOUNCE(true, 7); break;
                 case 8: PTK_BOUNCE_D(true, 8); break;
                 default: PTK_BOUNCE(true, 10); break;
@@ -1720,6 +1723,7 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
                 case 2: PTK_BOUNCE(false, 2); break;
                 case 3: PTK_BOUNCE(false, 3); break;
                 case 5: PTK_BOUNCE_D(false, 5); break;
+                case 21: PTK_BOUNCE_D(false, 21); break;
                 case 7: PTK_BOUNCE(false, 7); break;
                 case 8: PTK_BOUNCE_D(false, 8); break;
                 default: PTK_BOUNCE(false, 10); break;
@@ -2078,6 +2082,39 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
             culls[i] = make_cull_record(n, d, cond, nullptr);
         }
     }
+    // Bounding balls of the sphere nodes (DBall): centre = translation, radius = largest singular value of the 3x3 (power
+    // iteration on M^T M in double), a hair up.  Nodes whose box test is switched off (ill-conditioned matrices) get none.
+    struct DBall {
+        float cx, cy, cz, r;
+    };
+    std::vector<DBall> balls(sc->num_nodes, DBall{ 0.0f, 0.0f, 0.0f, -1.0f });
+    for (uint32_t i = 0; i < sc->num_nodes; ++i) {
+        const ptk_node_desc& n = sc->nodes[i];
+        if (n.shape_kind != PTK_SHAPE_SPHERE || !(std::fabs((double)nodes[i].wmax[0]) < 1e30)) continue;
+        const float* M = n.transform; // column-major M[c*4+r]
+        double A[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                A[a][b] = 0.0;
+                for (int r = 0; r < 3; ++r) A[a][b] += (double)M[a * 4 + r] * (double)M[b * 4 + r];
+            }
+        double x[3] = { 1.0, 0.9, 0.8 }, lambda = 0.0;
+        for (int it = 0; it < 200; ++it) {
+            double y[3];
+            for (int a = 0; a < 3; ++a) y[a] = A[a][0] * x[0] + A[a][1] * x[1] + A[a][2] * x[2];
+            lambda = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+            if (!(lambda > 0.0)) break;
+            for (int a = 0; a < 3; ++a) x[a] = y[a] / lambda;
+        }
+        // power iteration approaches the largest eigenvalue from below: bound it from above with the trace as well
+        const double trace = A[0][0] + A[1][1] + A[2][2];
+        double r2 = lambda * 1.0001;
+        if (!(r2 <= trace) || !(r2 >= trace / 3.0 * 0.9999)) r2 = trace; // not converged / degenerate: the trace is always an upper bound
+        const double r = std::sqrt(r2) * 1.00001;
+        if (!std::isfinite(r) || !std::isfinite((double)M[12]) || !std::isfinite((double)M[13]) || !std::isfinite((double)M[14])) continue;
+        balls[i] = DBall{ M[12], M[13], M[14], (float)r * 1.000001f };
+
+    }
     // The cull loop's margins, applied once: every ray that starts inside the scene's boxes (all rays after bounce 0: they
     // start a hair off a surface) has |o|_1 <= o1max, so its margin is at most cull_k * o1max + cull_c; the table holds the
     // boxes grown by that, rounded outwards.  Rays from further out are exempted from the per-ray cull in the kernel.
@@ -2103,6 +2140,17 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
             box[a][1] = std::nextafter((float)((double)box[a][1] + m), 3.402823466e+38f);
         }
     }
+    // A scene made of spheres only: the per-lane candidate lists cull against the balls, which then take the place of the
+    // world boxes in the node records (intersect_scene_lanelist<.., BALLS>; DNode::uses_uv bit 1 marks them)
+    bool all_balls = sc->num_nodes > 0;
+    for (uint32_t i = 0; i < sc->num_nodes; ++i) all_balls = all_balls && balls[i].r >= 0.0f;
+    if (all_balls)
+        for (uint32_t i = 0; i < sc->num_nodes; ++i) {
+            nodes[i].wmin[0] = balls[i].cx; nodes[i].wmin[1] = balls[i].cy; nodes[i].wmin[2] = balls[i].cz;
+            nodes[i].wmax[0] = balls[i].r;
+            nodes[i].uses_uv |= 2u;
+        }
+    c->all_balls = all_balls;
     std::vector<DLeaf> leaf_info(sc->num_nodes);
     for (uint32_t i = 0; i < sc->num_nodes; ++i) {
         DLeaf& lf = leaf_info[i];
@@ -2302,6 +2350,7 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
         case 2: PTK_BATCH(2); break;
         case 3: PTK_BATCH(3); break;
         case 5: PTK_BATCH(5); break;
+        case 21: PTK_BATCH(21); break;
         case 7: PTK_BATCH(7); break;
         case 8: PTK_BATCH(8); break;
         default: PTK_BATCH(10); break;
@@ -2546,6 +2595,7 @@ int ptk_render_aov_dev(ptk_ctx* c, uint32_t aov, uint64_t seed, uint64_t pixel_b
             case 2: PTK_AOV(2); break;
             case 3: PTK_AOV(3); break;
             case 5: PTK_AOV(5); break;
+            case 21: PTK_AOV(21); break;
             case 7: PTK_AOV(7); break;
             case 8: PTK_AOV(8); break;
             default: PTK_AOV(10); break;
@@ -2710,6 +2760,7 @@ int ptk_probe_shade_dev(ptk_ctx* c, uint64_t n, const float* origins, const floa
     case 2: PTK_PROBE(2); break;
     case 3: PTK_PROBE(3); break;
     case 5: PTK_PROBE(5); break;
+    case 21: PTK_PROBE(21); break;
     case 7: PTK_PROBE(7); break;
     case 8: PTK_PROBE(8); break;
     default: PTK_PROBE(10); break;

@@ -43,8 +43,25 @@ using namespace ptk;
 constexpr uint64_t kNoallocPaths = PTK_NOALLOC_MAX_PATHS;
 constexpr uint64_t kNoallocSegments = kNoallocPaths / 256;
 constexpr uint64_t kNoallocWordsPerPath = 13 + 13 + 3 + 1 + 2 + 9; // two queues, sample_L, pend_slot, pend_mask, pend_best
+#ifndef PTK_WALK_HEADS
+#define PTK_WALK_HEADS 32
+#endif
+#ifndef PTK_WALK_UNIT
+#define PTK_WALK_UNIT 64u
+#endif
+#ifndef PTK_WALK_RAYS
+#define PTK_WALK_RAYS 16ull
+#endif
+#ifndef PTK_WALK_GRABS
+#define PTK_WALK_GRABS 96u
+#endif
+// the walker's head counters (SplitBufs::walk_head): kWalkHeads per bounce, each on a 128-byte line, then the planned chunk per bounce
+constexpr uint32_t kWalkHeads = PTK_WALK_HEADS, kWalkHeadStride = 32u;
+constexpr uint32_t kWalkUnit = PTK_WALK_UNIT, kWalkUnitsPerSegment = 256u / kWalkUnit; // the walker's work unit: this many slots of a segment's parked list
+constexpr uint32_t kWalkPlanBase = PTK_MAX_DEPTH * kWalkHeads * kWalkHeadStride;
+constexpr uint32_t kSplitCounters = kWalkPlanBase + PTK_MAX_DEPTH;
 constexpr uint64_t kNoallocBytes =
-    kNoallocPaths * kNoallocWordsPerPath * 4 + (kNoallocSegments * (PTK_MAX_DEPTH + 1) + 2 * PTK_MAX_DEPTH) * 4 + 8 * 256;
+    kNoallocPaths * kNoallocWordsPerPath * 4 + (kNoallocSegments * (PTK_MAX_DEPTH + 1) + kSplitCounters) * 4 + 8 * 256;
 static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
 
 namespace {
@@ -401,13 +418,14 @@ struct SplitBufs {
     float* q[2];                   // ray queues: kStateFields arrays of `cap` floats each, 256-slot segments
     uint32_t* seg_count;           // [PTK_MAX_DEPTH][num_segments] live rays of a segment entering bounce b
     uint32_t* seg_pend;            // [num_segments] parked rays of a segment (current bounce)
-    uint32_t* walk_head;           // [PTK_MAX_DEPTH] next unit the walker hands out; [PTK_MAX_DEPTH + b]: units per grab (k_walk_plan)
+    uint32_t* walk_head;           // [kSplitCounters]: per bounce kWalkHeads counters of chunks handed out (a cache line each), then
+                                   // at [kWalkPlanBase + b] the units per chunk (k_walk_plan)
     uint32_t* pend_slot;           // per parked ray (segment * 256 + i): its queue slot (render) / ray index (batch)
     unsigned long long* pend_mask; //   its tree nodes: bits over DScene::tree_nodes
     float* pend_best;              //   9 arrays of `cap`: d0, node, prim, a0..a2, pw of its best hit so far
     uint64_t cap;
     uint32_t num_segments;
-    uint32_t walk_chunk;           // quarter-segment units the walker takes per atomic (host: ~24 grabs per wave)
+    uint32_t walk_chunk;           // quarter-segment units the walker takes per atomic (host: ~96 grabs per wave)
 };
 
 __device__ __forceinline__ void queue_store(float* __restrict__ q, uint64_t cap, uint32_t ws, V3 o, V3 d, V3 T, V3 L,
@@ -554,9 +572,11 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch_split(const DScene S
 // are at least 33 lanes IDLE or DONE after the START/FIN step, so either 16 are IDLE (refill) or 17 are
 // DONE (shade); once the list is dry the walk loop runs the remaining lanes to the end.
 // How many units the walker takes per atomic, from what k_bounce_split parked.  Every grab is one atomic on
-// one address, about 8 ns each back to back: 65536 grabs are half a millisecond even when nearly nothing is
-// parked (an open scene after bounce 0).  With P parked rays the walker aims at ~48 rays per grab, but no
-// fewer than two grabs per wave and no more than the host's figure for full segments (base_chunk).
+// one of kWalkHeads addresses, about 8 ns each back to back at one address: 65536 grabs were half a millisecond
+// even when nearly nothing is parked (an open scene after bounce 0).  With P parked rays the walker aims at
+// ~16 rays per grab (48 while there was one head: small grabs even the waves out, and spread over 32 heads they
+// no longer queue), but no fewer than two grabs per wave and no more than the host's figure for full segments
+// (base_chunk).
 __global__ __launch_bounds__(1024) void k_walk_plan(const uint32_t* __restrict__ seg_pend, uint32_t num_segments, uint32_t base_chunk,
                                                    uint32_t waves, uint32_t* __restrict__ chunk_out)
 {
@@ -569,15 +589,15 @@ __global__ __launch_bounds__(1024) void k_walk_plan(const uint32_t* __restrict__
     if (threadIdx.x == 0u) {
         unsigned long long parked = 0ull;
         for (int w = 0; w < 16; ++w) parked += part[w];
-        const unsigned long long units = (unsigned long long)num_segments * 4ull;
+        const unsigned long long units = (unsigned long long)num_segments * kWalkUnitsPerSegment;
         const unsigned long long most = units / (base_chunk ? base_chunk : 1u); // grabs at the host's chunk
-        unsigned long long grabs = parked / 48ull; // measured: 12-48 rays per grab are level, 96 and more lose to imbalance
+        unsigned long long grabs = parked / PTK_WALK_RAYS;
         if (grabs < 2ull * waves) grabs = 2ull * waves;
         if (grabs > most) grabs = most;
         if (grabs < 1ull) grabs = 1ull;
         unsigned long long chunk = units / grabs;
         if (chunk < base_chunk) chunk = base_chunk;
-        if (chunk >= 4ull) chunk &= ~3ull; // whole segments once a grab spans one
+        if (chunk >= kWalkUnitsPerSegment) chunk &= ~(unsigned long long)(kWalkUnitsPerSegment - 1u); // whole segments once a grab spans one
         if (chunk < 1ull) chunk = 1ull;
         *chunk_out = (uint32_t)(chunk > 0x40000000ull ? 0x40000000ull : chunk);
     }
@@ -599,11 +619,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     __shared__ WalkLds wave_lds[kBlock / 64];
     const uint32_t lane = lane_id();
     const uint32_t bounce = BATCH ? 0u : bounce_in;
-    const uint32_t nunits = Q.num_segments * 4u; // work units: quarters (64 slots) of the segments' parked lists
-    const uint32_t planned = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.walk_head[PTK_MAX_DEPTH + bounce]);
+    const uint32_t nunits = Q.num_segments * kWalkUnitsPerSegment; // work units: kWalkUnit slots of a segment's parked list
+    const uint32_t planned = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.walk_head[kWalkPlanBase + bounce]);
     const uint32_t walk_chunk = planned ? planned : Q.walk_chunk; // k_walk_plan's figure for this bounce
     const uint64_t cap = Q.cap;
     const float* __restrict__ qin = Q.q[bounce & 1u];
+    // Work is handed out in chunks of walk_chunk units by atomics.  One head counter would see every grab of all 4096 waves
+    // (5-7 us per grab in the queue at that address, 6 % of the walker's time); chunk j belongs to head j % kWalkHeads
+    // instead, each head on a cache line of its own, and a wave starts at the head of its workgroup's number and moves on
+    // to the next head when one runs dry: after kWalkHeads dry heads the lists are empty.
+    const uint32_t nchunks = (nunits + walk_chunk - 1u) / walk_chunk;
+    uint32_t head = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) % kWalkHeads, heads_dry = 0u;
+    uint32_t* __restrict__ const heads = Q.walk_head + bounce * kWalkHeads * kWalkHeadStride;
 
     WalkLds& my_lds = wave_lds[threadIdx.x >> 6];
     const LdsStack stack{ &my_lds.stack_i[0][lane], &my_lds.stack_t[0][lane] };
@@ -620,8 +647,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     // The ray's best hit so far stays in its parked record (pend_best): a walk works in the node's local space
     // and never looks at it; it is read and, if beaten, rewritten when a tree node's walk ends (FIN).
 
+    [[maybe_unused]] const unsigned long long clk_begin = PTK_CLOCK();
+    [[maybe_unused]] unsigned long long acc_d = 0ull, acc_p = 0ull, acc_l = 0ull, acc_r = 0ull, acc_f = 0ull, acc_a = 0ull, acc_n = 0ull; // -DPTK_STATS: clocks per kind of pass
     for (;;) {
         // refill
+        [[maybe_unused]] const unsigned long long clk_r0 = PTK_CLOCK();
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == IDLE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if (!dry && nidle >= kRefillIdle) {
@@ -629,22 +659,31 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             while (idle_left != 0ull) {
                 while (!dry && pos >= cnt) { // on to the next unit (a quarter of a segment's parked list) with rays
                     if (next_unit >= chunk_end) {
-                        uint32_t base = 0u;
-                        if (lane == 0u) base = atomicAdd(Q.walk_head + bounce, walk_chunk);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        if (base >= nunits) {
-                            dry = true;
-                            break;
+                        uint32_t k = 0u;
+                        [[maybe_unused]] const unsigned long long clk_a0 = PTK_CLOCK();
+                        if (lane == 0u) k = atomicAdd(heads + head * kWalkHeadStride, 1u);
+                        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                        acc_a += PTK_CLOCK() - clk_a0;
+                        acc_n += 1ull;
+                        const uint32_t chunk = k * kWalkHeads + head;
+                        if (chunk >= nchunks) { // this head has nothing left
+                            head = head + 1u == kWalkHeads ? 0u : head + 1u;
+                            if (++heads_dry == kWalkHeads) {
+                                dry = true;
+                                break;
+                            }
+                            continue;
                         }
+                        const uint32_t base = chunk * walk_chunk;
                         next_unit = base;
                         chunk_end = base + walk_chunk < nunits ? base + walk_chunk : nunits;
                     }
                     const uint32_t unit = next_unit++;
-                    seg_cur = unit >> 2;
+                    seg_cur = unit / kWalkUnitsPerSegment;
                     const uint32_t in_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.seg_pend[seg_cur]);
-                    pos = (unit & 3u) * 64u;
-                    cnt = in_seg < pos + 64u ? in_seg : pos + 64u;
-                    if (pos >= in_seg) next_unit = (unit | 3u) + 1u; // the segment's later quarters are empty too
+                    pos = (unit % kWalkUnitsPerSegment) * kWalkUnit;
+                    cnt = in_seg < pos + kWalkUnit ? in_seg : pos + kWalkUnit;
+                    if (pos >= in_seg) next_unit = (unit | (kWalkUnitsPerSegment - 1u)) + 1u; // the segment's later units are empty too
                 }
                 if (dry) break;
                 const uint32_t avail = cnt - pos, left = (uint32_t)__popcll(idle_left);
@@ -663,13 +702,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
                     }
                     state = START;
                 }
-                PTK_STAT(S, 24, take);
-                PTK_STAT(S, 25, 1);
+                PTK_STAT_FINE(S, 24, take);
+                PTK_STAT_FINE(S, 25, 1);
                 idle_left &= ~__builtin_amdgcn_ballot_w64(mine_now);
                 pos += take;
             }
         }
 
+        [[maybe_unused]] const unsigned long long clk_r1 = PTK_CLOCK();
+        acc_r += clk_r1 - clk_r0;
         // FIN -> fold the node's result into the ray's best hit; START -> next tree node or DONE
         while (__builtin_amdgcn_ballot_w64(state == FIN || state == START) != 0ull) {
             const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + node);
@@ -716,8 +757,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
         // leaf (next: its triangles), or between nodes (next: a pop, which re-enters a node with six IEEE
         // divides).  Each pass serves the most populated place for all its lanes at once, so the pooled
         // leaf stage and the pops run for many lanes instead of being dragged along by every descend step.
+        acc_f += PTK_CLOCK() - clk_r1;
         const uint32_t walk_min = dry ? 1u : kWalkMin;
         for (;;) {
+            [[maybe_unused]] const unsigned long long clk_p0 = PTK_CLOCK();
             if (state == WALK && W.cur == kWalkNone) state = FIN;
             const bool walking = state == WALK;
             const bool at_pop = walking && W.cur == kWalkPop;
@@ -731,20 +774,22 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             // lanes served per instruction spent: a descend step costs about 135 VALU instructions, a pop 90,
             // a leaf stage 250 or more
             if (2u * n_node >= n_leaf && 2u * n_node >= 3u * n_pop) {
-                PTK_STAT(S, 22, 1);
-                PTK_STAT(S, 23, n_node);
+                PTK_STAT_FINE(S, 22, 1);
+                PTK_STAT_FINE(S, 23, n_node);
 #ifdef PTK_WALK_INLINE_POP
                 if (at_node) walk_descend_step<false>(W, S, stack, stack_cap);
 #else
                 if (at_node) walk_descend_step<true>(W, S, stack, stack_cap);
 #endif
+                acc_d += PTK_CLOCK() - clk_p0;
             } else if (3u * n_pop >= n_leaf) {
-                PTK_STAT(S, 29, 1);
-                PTK_STAT(S, 30, n_pop);
+                PTK_STAT_FINE(S, 29, 1);
+                PTK_STAT_FINE(S, 30, n_pop);
                 if (at_pop) walk_pop(W, stack);
+                acc_p += PTK_CLOCK() - clk_p0;
             } else {
-                PTK_STAT(S, 26, 1);
-                PTK_STAT(S, 27, n_leaf);
+                PTK_STAT_FINE(S, 26, 1);
+                PTK_STAT_FINE(S, 27, n_leaf);
                 walk_leaf_stage(W, S, at_leaf, my_lds);
                 if (at_leaf && W.leaf_done >= (W.cb & kKdCountMask)) {
                     W.leaf_done = 0u;
@@ -754,6 +799,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
                     W.cur = kWalkPop;
 #endif
                 }
+                acc_l += PTK_CLOCK() - clk_p0;
             }
         }
 
@@ -762,6 +808,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
         if (state == DONE) state = IDLE;
         if (dry && __builtin_amdgcn_ballot_w64(state != IDLE) == 0ull) break;
     }
+    PTK_STAT(S, 13, acc_d);
+    PTK_STAT(S, 14, acc_p);
+    PTK_STAT(S, 15, acc_l);
+    PTK_STAT(S, 17, acc_r);
+    PTK_STAT(S, 19, acc_f);
+    PTK_STAT(S, 22, acc_a);
+    PTK_STAT(S, 23, acc_n);
+    PTK_STAT(S, 20, PTK_CLOCK() - clk_begin);
+    PTK_STAT(S, 21, 1);
 }
 
 // Shades the parked rays of a segment once the walker has finished their hits: dense again (one lane
@@ -1511,17 +1566,17 @@ bool split_mode(const ptk_ctx* c)
 }
 
 constexpr uint32_t kWalkBlocks = 1024; // persistent walker grid: 4 resident waves on each of the 1024 SIMDs
-constexpr uint32_t kSplitCounters = 2 * PTK_MAX_DEPTH; // walk_head[bounce], then the walker's chunk per bounce (k_walk_plan)
 
 // Walker work units are quarter segments; small launches take them one at a time (short tail), large
-// ones in chunks so that the single head counter sees about 24 atomics per resident wave (measured on the
-// 5 M-triangle scene: 6 -> 712, 12 -> 795, 24 -> 832, 48 -> 823 Mpaths/s).
+// ones in chunks so that the head counters see about 96 atomics per resident wave (with one head counter 24 was
+// the optimum on the 5 M-triangle scene: 6 -> 712, 12 -> 795, 24 -> 832, 48 -> 823 Mpaths/s; with 32 heads
+// 24 -> 928, 48 -> 964, 96 -> 971).
 uint32_t walk_chunk_for(uint32_t num_segments)
 {
-    const uint64_t units = (uint64_t)num_segments * 4u;
-    const uint64_t chunk = units / (uint64_t(kWalkBlocks) * (kBlock / 64) * 24u);
+    const uint64_t units = (uint64_t)num_segments * kWalkUnitsPerSegment;
+    const uint64_t chunk = units / (uint64_t(kWalkBlocks) * (kBlock / 64) * PTK_WALK_GRABS);
     if (chunk < 1u) return 1u;
-    return (uint32_t)(chunk >= 4u ? (chunk & ~3ull) : chunk); // whole segments once a grab spans one
+    return (uint32_t)(chunk >= kWalkUnitsPerSegment ? (chunk & ~uint64_t(kWalkUnitsPerSegment - 1u)) : chunk); // whole segments once a grab spans one
 }
 
 constexpr uint64_t kDeviceKdMinTriangles = 32768; // PTK_OPT_DEVICE_KD = 2: meshes at least this large build on the GPU
@@ -1627,7 +1682,7 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
             if (A.dense) k_clear_u32<<<dim3(((PTK_MAX_DEPTH + 1) * kBuckets + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream>>>(R.bucket, (PTK_MAX_DEPTH + 1) * kBuckets);
             const dim3 grid(A.num_segments), block(kBlock);
             if (split) {
-                k_clear_u32<<<dim3(1), dim3(kBlock), 0, c->stream>>>(R.split_counters, kSplitCounters);
+                k_clear_u32<<<dim3((kSplitCounters + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream>>>(R.split_counters, kSplitCounters);
                 SplitBufs Q{};
                 Q.q[0] = R.state;
                 Q.q[1] = R.state2;
@@ -1649,7 +1704,7 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
                         else k_bounce_split<false><<<grid, block, 0, c->stream>>>(c->S, c->V, A, Q);
                     }
                     k_walk_plan<<<1, 1024, 0, c->stream>>>(Q.seg_pend, Q.num_segments, Q.walk_chunk, wb * (kBlock / 64),
-                                                            Q.walk_head + PTK_MAX_DEPTH + b);
+                                                            Q.walk_head + kWalkPlanBase + b);
                     {
                         LaunchTimer lt(c, PTK_KERNEL_WALK);
                         k_walk<false><<<dim3(wb), block, 0, c->stream>>>(c->S, b, Q, BatchIO{});
@@ -2338,7 +2393,7 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);
         k_intersect_batch_split<<<g, b, 0, c->stream>>>(c->S, B, Q);
         const uint32_t wb = blocks < kWalkBlocks ? blocks : kWalkBlocks;
-        k_walk_plan<<<1, 1024, 0, c->stream>>>(Q.seg_pend, Q.num_segments, Q.walk_chunk, wb * (kBlock / 64), Q.walk_head + PTK_MAX_DEPTH);
+        k_walk_plan<<<1, 1024, 0, c->stream>>>(Q.seg_pend, Q.num_segments, Q.walk_chunk, wb * (kBlock / 64), Q.walk_head + kWalkPlanBase);
         k_walk<true><<<dim3(wb), b, 0, c->stream>>>(c->S, 0u, Q, B);
         k_batch_parked<<<g, b, 0, c->stream>>>(c->S, B, Q);
     } else {

@@ -150,14 +150,24 @@ struct DScene {
 #ifdef PTK_STATS
 #define PTK_STAT(S, k, v) do { if (lane_id() == 0u && (blockIdx.x & 15u) == 0u) atomicAdd((S).stats + (k), (unsigned long long)(v)); } while (0) // every 16th block: same-line atomics are slow enough to distort the clocks
 #define PTK_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
+#ifdef PTK_STATS_COARSE // clocks only: the walker's per-pass counters are atomics too and stretch what they count
+#define PTK_STAT_FINE(S, k, v) do { } while (0)
+#else
+#define PTK_STAT_FINE(S, k, v) PTK_STAT(S, k, v)
+#endif
 // inside divergent code: counts one event per wave (k) and the lanes taking part (k + 1)
+#ifdef PTK_STATS_COARSE
+#define PTK_STAT_ACTIVE(S, k) do { } while (0)
+#else
 #define PTK_STAT_ACTIVE(S, k) do { const uint64_t m_ = __builtin_amdgcn_ballot_w64(true); \
     if (lane_id() == (uint32_t)__builtin_ctzll(m_)) { atomicAdd((S).stats + (k), 1ull); atomicAdd((S).stats + (k) + 1, (unsigned long long)__popcll(m_)); } } while (0)
+#endif
 #define PTK_STAT_ACTIVE_NS(k) do { } while (0)
 #else
 #define PTK_STAT_ACTIVE(S, k) do { } while (0)
 #define PTK_STAT_ACTIVE_NS(k) do { } while (0)
 #define PTK_STAT(S, k, v) do { } while (0)
+#define PTK_STAT_FINE(S, k, v) do { } while (0)
 #define PTK_CLOCK() 0ull
 #endif
 
@@ -1676,7 +1686,7 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const uint64_t wm = __builtin_amdgcn_ballot_w64(cnt != 0u);
     if (total == 0u) return;
-    PTK_STAT(S, 28, total);
+    PTK_STAT_FINE(S, 28, total);
     L.key[lane] = kKeyNone;
     L.start_mask[lane] = 0ull;
     if (cnt != 0u) L.owner[mbcnt64(wm)] = (uint8_t)lane;
@@ -1698,13 +1708,13 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
         const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
         float dd = 0.0f;
         V3 bar = mk(0.0f, 0.0f, 0.0f), p = mk(0.0f, 0.0f, 0.0f);
-        PTK_STAT(S, 18, 1);
+        PTK_STAT_FINE(S, 18, 1);
 #ifdef PTK_STATS
         { // how many items the two side tests of scene.cpp:149,158 alone would reject
             const V3 v0s = mk(q0.x, q0.y, q0.z), Ns = mk(q0.w, q1.x, q1.y);
             const bool side_out = valid && (dot(co - v0s, Ns) < 0 || dot(cd, Ns) >= 0);
             const uint64_t so = __builtin_amdgcn_ballot_w64(side_out);
-            PTK_STAT(S, 31, __popcll(so));
+            PTK_STAT_FINE(S, 31, __popcll(so));
         }
 #endif
         const bool hit = valid && tri_eval(q0, q1, q2, q3, co, cd, dd, bar, p) && dd < 3.402823466e+38f;

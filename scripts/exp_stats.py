@@ -44,4 +44,12 @@ if v[22]:
           f"leaf stages {v[26]} (avg leaf lanes {v[27]/max(1,v[26]):.1f}), triangle items {v[28]} ({v[28]/rays:.1f} per ray) in {v[18]} iterations "
           f"({v[28]/max(1,v[18]):.1f} per iteration); pop passes {v[29]} (avg lanes {v[30]/max(1,v[29]):.1f}); "
           f"items the side tests alone reject: {v[31]} ({100.0*v[31]/max(1,v[28]):.1f} %)")
+if v[21]:
+    if True:
+        wv = v[21]
+        print(f"walker clocks per persistent wave ({wv} sampled): total {v[20]/wv:.0f}; descend {v[13]/wv:.0f} ({v[13]/max(1,v[22]):.0f} per pass); "
+              f"pop {v[14]/wv:.0f} ({v[14]/max(1,v[29]):.0f} per pass); leaf {v[15]/wv:.0f} ({v[15]/max(1,v[26]):.0f} per stage); "
+              f"refill {v[17]/wv:.0f}; fin/start {v[19]/wv:.0f}")
+        if os.environ.get("PTK_STATS_COARSE"):
+            print(f"  (coarse build) of the refill: {v[22]/wv:.0f} clocks in {v[23]/wv:.1f} grabs per wave ({v[22]/max(1,v[23]):.0f} per grab)")
 ctx.close()

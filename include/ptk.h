@@ -347,7 +347,7 @@ int ptk_counters_download_async(ptk_ctx* ctx, ptk_counters* host_out);
  * tested in the uniform loop and each lane then visits only the nodes whose box it pierced;
  * 2 (default) = 0 for the coherent primary rays of bounce 0 (1 if PTK_OPT_NODE_CULL applies), 1 for
  * later bounces and for ptk_intersect_batch.  No reference counterpart. */
-enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5, PTK_OPT_DEVICE_KD = 6, PTK_OPT_WALK_STACK = 7, PTK_OPT_COMPACT = 8, PTK_OPT_FUSE = 9 };
+enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_OPT_BALANCE = 4, PTK_OPT_SPLIT = 5, PTK_OPT_DEVICE_KD = 6, PTK_OPT_WALK_STACK = 7, PTK_OPT_COMPACT = 8, PTK_OPT_FUSE = 9, PTK_OPT_OVERLAP = 10 };
 /* PTK_OPT_KD_PRUNE: how a multi-node KD-tree is walked (mesh::intersect_internal,
  * scene.cpp:188-212).  0 = the reference's order, every box-hit node is visited;
  * 1 (default) = near child first (by the sign of the ray direction on the split axis),
@@ -386,7 +386,12 @@ enum { PTK_OPT_TRAVERSAL = 1, PTK_OPT_KD_PRUNE = 2, PTK_OPT_NODE_CULL = 3, PTK_O
  * ray in registers from bounce to bounce: no ray queue traffic, no compaction, one launch per chain instead of five; a path
  * that ends early idles its lane, so this only pays where nearly all paths live five bounces (a closed scene).  0 = a kernel
  * per bounce; 2 (default) = 1 once the counters of the chunks rendered so far show at least 4.75 rays per path, else 0.
- * Same image, same counters. */
+ * Same image, same counters.
+ * PTK_OPT_OVERLAP: scenes with KD-trees (PTK_OPT_SPLIT).  1 (default) = a ptk_render_samples_dev call of at least 2^20 paths
+ * is issued as two launch chains over the two halves of its pixel range, the second on a stream the context owns, forked
+ * from and joined to the context's stream with events: one chain's kernel tails (a persistent walker launch waits for its
+ * slowest wave) are filled with the other's work.  Stream order as seen by the caller does not change; the sums are the
+ * same bit for bit.  0 = one chain.  Calls whose launches are timed (ptk_ctx_enable_timing) always run as one chain. */
 int ptk_ctx_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Per-kernel launch timing with HIP events on the context's stream (bench.py's

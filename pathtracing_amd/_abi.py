@@ -121,6 +121,7 @@ PTK_OPT_DEVICE_KD = 6
 PTK_OPT_WALK_STACK = 7
 PTK_OPT_COMPACT = 8
 PTK_OPT_FUSE = 9
+PTK_OPT_OVERLAP = 10
 PTK_KERNEL_NAMES = ["k_bounce<true>", "k_bounce<false>", "k_accumulate", "k_intersect_batch", "k_walk", "k_shade_parked", "k_bounce_fused"]
 
 # name -> (restype, argtypes); every symbol include/ptk.h declares.

@@ -46,6 +46,21 @@ constexpr uint64_t kNoallocWordsPerPath = 13 + 13 + 3 + 1 + 2 + 9; // two queues
 #ifndef PTK_WALK_HEADS
 #define PTK_WALK_HEADS 32
 #endif
+#ifndef PTK_OVERLAP_MIN_PATHS
+#define PTK_OVERLAP_MIN_PATHS (1ull << 20)
+#endif
+#ifndef PTK_OVERLAP_FIRST_PCT
+#define PTK_OVERLAP_FIRST_PCT 50
+#endif
+#ifndef PTK_OVERLAP_WALK_BLOCKS
+#define PTK_OVERLAP_WALK_BLOCKS 0
+#endif
+#ifndef PTK_DRAIN_FIN
+#define PTK_DRAIN_FIN 0
+#endif
+#ifndef PTK_DRAIN_LANES
+#define PTK_DRAIN_LANES 0
+#endif
 #ifndef PTK_WALK_UNIT
 #define PTK_WALK_UNIT 64u
 #endif
@@ -633,7 +648,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     uint32_t* __restrict__ const heads = Q.walk_head + bounce * kWalkHeads * kWalkHeadStride;
 
     WalkLds& my_lds = wave_lds[threadIdx.x >> 6];
+#ifdef PTK_STATS
+    const LdsStack stack{ &my_lds.stack_i[0][lane], &my_lds.stack_t[0][lane], S.stats };
+#else
     const LdsStack stack{ &my_lds.stack_i[0][lane], &my_lds.stack_t[0][lane] };
+#endif
     const int stack_cap = (int)S.walk_stack < kWalkStack ? (int)S.walk_stack : kWalkStack;
     KdWalk W;
     walk_begin(W, S, DMesh{ 0u, 0u, 0u, 0u }, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), false);
@@ -648,7 +667,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     // and never looks at it; it is read and, if beaten, rewritten when a tree node's walk ends (FIN).
 
     [[maybe_unused]] const unsigned long long clk_begin = PTK_CLOCK();
-    [[maybe_unused]] unsigned long long acc_d = 0ull, acc_p = 0ull, acc_l = 0ull, acc_r = 0ull, acc_f = 0ull, acc_a = 0ull, acc_n = 0ull; // -DPTK_STATS: clocks per kind of pass
+    [[maybe_unused]] unsigned long long acc_d = 0ull, acc_p = 0ull, acc_l = 0ull, acc_r = 0ull, acc_f = 0ull, acc_a = 0ull, acc_n = 0ull, clk_dry = 0ull; // -DPTK_STATS: clocks per kind of pass
     for (;;) {
         // refill
         [[maybe_unused]] const unsigned long long clk_r0 = PTK_CLOCK();
@@ -670,6 +689,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
                             head = head + 1u == kWalkHeads ? 0u : head + 1u;
                             if (++heads_dry == kWalkHeads) {
                                 dry = true;
+                                clk_dry = PTK_CLOCK();
                                 break;
                             }
                             continue;
@@ -771,6 +791,29 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             const uint32_t n_pop = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_pop));
             const uint32_t n_walk = n_node + n_leaf + n_pop;
             if (n_walk < walk_min || n_walk == 0u) break;
+#if PTK_DRAIN_FIN
+            // the lists are dry: a lane whose walk has just ended goes on to its next tree at once instead of waiting for the
+            // wave's last walk
+            if (dry && __builtin_amdgcn_ballot_w64(state == FIN) != 0ull) break;
+#endif
+#if PTK_DRAIN_LANES
+            // Dry lists and a few rays left: the wave is waiting for memory, not for instructions, and every pass that serves
+            // one place only leaves the rays in the other two standing.  One pass then serves all three, in the order in
+            // which a ray moves through them (leaf -> pop -> descend).
+            if (dry && n_walk <= PTK_DRAIN_LANES) {
+                if (n_leaf != 0u) {
+                    walk_leaf_stage(W, S, at_leaf, my_lds);
+                    if (at_leaf && W.leaf_done >= (W.cb & kKdCountMask)) {
+                        W.leaf_done = 0u;
+                        W.cur = kWalkPop;
+                    }
+                }
+                if (state == WALK && W.cur == kWalkPop) walk_pop(W, stack);
+                if (state == WALK && W.cur != kWalkNone && W.cur != kWalkPop && (W.cb & kKdCountMask) == 0u)
+                    walk_descend_step<true>(W, S, stack, stack_cap);
+                continue;
+            }
+#endif
             // lanes served per instruction spent: a descend step costs about 135 VALU instructions, a pop 90,
             // a leaf stage 250 or more
             if (2u * n_node >= n_leaf && 2u * n_node >= 3u * n_pop) {
@@ -817,6 +860,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     PTK_STAT(S, 23, acc_n);
     PTK_STAT(S, 20, PTK_CLOCK() - clk_begin);
     PTK_STAT(S, 21, 1);
+#if defined(PTK_STATS) && defined(PTK_STATS_COARSE)
+    { // per bounce (stats hold one launch chain): clocks of every wave summed, their number, the slowest wave
+        const unsigned long long t = PTK_CLOCK() - clk_begin;
+        if (lane == 0u) {
+            atomicAdd(S.stats + 32 + bounce, t);
+            atomicAdd(S.stats + 40 + bounce, 1ull);
+            atomicMax(S.stats + 48 + bounce, t);
+            atomicAdd(S.stats + 56, PTK_CLOCK() - clk_dry); // from "the lists are dry" to the wave's end
+            atomicMax(S.stats + 57 + bounce, PTK_CLOCK() - clk_dry);
+
+        }
+    }
+#endif
 }
 
 // Shades the parked rays of a segment once the walker has finished their hits: dense again (one lane
@@ -1121,6 +1177,9 @@ struct ptk_ctx {
     int walk_stack = 64; // PTK_OPT_WALK_STACK (clamped to the kernels' own capacity)
     int compact = 2;     // PTK_OPT_COMPACT
     int fuse = 2;        // PTK_OPT_FUSE
+    int overlap = 1;     // PTK_OPT_OVERLAP
+    hipStream_t side_stream = nullptr; // second launch chain of a split-mode call (PTK_OPT_OVERLAP)
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int exp_stage = 0;   // PTK_EXP builds: stage limit of bounce 2 (environment PTK_EXP_STAGE)
     uint32_t num_trees = 0; // nodes of class kClassTree
 
@@ -1579,6 +1638,8 @@ uint32_t walk_chunk_for(uint32_t num_segments)
     return (uint32_t)(chunk >= kWalkUnitsPerSegment ? (chunk & ~uint64_t(kWalkUnitsPerSegment - 1u)) : chunk); // whole segments once a grab spans one
 }
 
+constexpr uint64_t kOverlapMinPaths = PTK_OVERLAP_MIN_PATHS; // PTK_OPT_OVERLAP: smaller calls stay one launch chain
+constexpr uint64_t kOverlapFirstPct = PTK_OVERLAP_FIRST_PCT; // share of the pixels (and of the buffers) in the first chain
 constexpr uint64_t kDeviceKdMinTriangles = 32768; // PTK_OPT_DEVICE_KD = 2: meshes at least this large build on the GPU
 
 // The launch chain of ptk_render_samples_dev / ptk_render_samples_noalloc_dev over the scratch buffers `R`
@@ -1596,6 +1657,7 @@ struct RenderBufs {
     float* state_other;           // PTK_OPT_COMPACT across segments: second queue (null = compact inside the segment)
     uint32_t* bucket;             //   and its bucket counters
     bool fused;                   // PTK_OPT_FUSE: all bounces in one kernel (k_bounce_fused), no queue
+    uint32_t walk_blocks;         // persistent workgroups of k_walk (0 = kWalkBlocks)
     uint64_t cap;
 };
 
@@ -1695,7 +1757,8 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
                 Q.pend_mask = R.pend_mask;
                 Q.pend_best = R.pend_best;
                 Q.cap = cap;
-                const uint32_t wb = A.num_segments < kWalkBlocks ? A.num_segments : kWalkBlocks;
+                const uint32_t wb_max = R.walk_blocks ? R.walk_blocks : kWalkBlocks;
+                const uint32_t wb = A.num_segments < wb_max ? A.num_segments : wb_max;
                 for (uint32_t b = 0; b < PTK_MAX_DEPTH; ++b) {
                     A.bounce = b;
                     {
@@ -1829,6 +1892,13 @@ int ptk_ctx_create(int device, ptk_ctx** out)
     if (hipHostMalloc((void**)&c->h_snapshot, 2 * sizeof(unsigned long long)) != hipSuccess) c->h_snapshot = nullptr;
     if (c->h_snapshot && hipEventCreateWithFlags(&c->snapshot_ev, hipEventDisableTiming) != hipSuccess) c->snapshot_ev = nullptr;
     (void)hipGetLastError(); // without the snapshot PTK_OPT_COMPACT = 2 simply stays in place
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
+    if (c->side_stream && (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipStreamDestroy(c->side_stream);
+        c->side_stream = nullptr;
+    }
+    (void)hipGetLastError(); // without the side stream PTK_OPT_OVERLAP does nothing
     if (const char* e = std::getenv("PTK_EXP_STAGE")) c->exp_stage = std::atoi(e);
     noalloc_scratch_init(device); // `device` is current here
     *out = c;
@@ -1847,6 +1917,12 @@ void ptk_ctx_destroy(ptk_ctx* c)
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->snapshot_ev) (void)hipEventDestroy(c->snapshot_ev);
     if (c->h_snapshot) (void)hipHostFree(c->h_snapshot);
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -2313,8 +2389,8 @@ int ptk_scene_upload(ptk_ctx* c, const ptk_scene_desc* sc)
 #ifdef PTK_STATS
     {
         void* sp = nullptr;
-        PTK_HIP(c, hipMalloc(&sp, 32 * sizeof(unsigned long long)));
-        PTK_HIP(c, hipMemset(sp, 0, 32 * sizeof(unsigned long long)));
+        PTK_HIP(c, hipMalloc(&sp, 64 * sizeof(unsigned long long)));
+        PTK_HIP(c, hipMemset(sp, 0, 64 * sizeof(unsigned long long)));
         c->allocs.push_back(sp);
         S.stats = static_cast<unsigned long long*>(sp);
     }
@@ -2512,7 +2588,7 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
         PTK_HIP(c, hipStreamSynchronize(c->stream));
         free_split(c);
         PTK_HIP(c, hipMalloc((void**)&c->d_state2, cap * kStateFields * sizeof(float)));
-        PTK_HIP(c, hipMalloc((void**)&c->d_split_counters, kSplitCounters * sizeof(uint32_t)));
+        PTK_HIP(c, hipMalloc((void**)&c->d_split_counters, 2 * kSplitCounters * sizeof(uint32_t))); // one set per launch chain (PTK_OPT_OVERLAP)
         PTK_HIP(c, hipMalloc((void**)&c->d_seg_pend, (cap / kBlock) * sizeof(uint32_t)));
         PTK_HIP(c, hipMalloc((void**)&c->d_pend_slot, cap * sizeof(uint32_t)));
         PTK_HIP(c, hipMalloc((void**)&c->d_pend_mask, cap * sizeof(unsigned long long)));
@@ -2561,7 +2637,48 @@ int ptk_render_samples_dev(ptk_ctx* c, uint64_t seed, uint64_t pixel_begin, uint
     // per-launch events cost a few microseconds of GPU pipeline each (5 % on a chain of short kernels): with
     // ptk_ctx_enable_timing(n > 1) only every n-th call carries them
     c->timing_hold = c->timing && (c->timing_tick++ % c->timing_every) != 0u;
-    const int rc = render_samples_impl(c, R, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb, accumulate);
+    // PTK_OPT_OVERLAP: a walker launch ends with its slowest wave (a quarter of its time is waves that have run out of rays
+    // waiting for that one), and so does every other kernel of the chain in its own small way.  A large split-mode call
+    // therefore goes out as TWO chains over the two halves of its pixel range, each on half of the buffers, the second
+    // on a stream of its own between two events: the GPU fills one chain's tails with the other's work.  Same samples,
+    // same sums (a pixel's samples stay in one chain, in the same order).  Calls whose launches are being timed
+    // (ptk_ctx_enable_timing) run as one chain, so that the durations are those of kernels running alone.
+    const uint64_t cap1 = (cap * kOverlapFirstPct / 100u) / kBlock * kBlock, cap2 = (cap - cap1) / kBlock * kBlock;
+    const bool timed = c->timing && !c->timing_hold;
+    int rc;
+    if (split && c->overlap && c->side_stream && !timed && pixel_count >= 2 && cap1 >= kBlock && cap2 >= kBlock &&
+        pixel_count * (uint64_t)sample_count >= kOverlapMinPaths) {
+        RenderBufs R1 = R, R2 = R;
+        R1.cap = cap1;
+        R2.cap = cap2;
+        R1.walk_blocks = R2.walk_blocks = PTK_OVERLAP_WALK_BLOCKS;
+        R2.state = R.state + kStateFields * cap1;
+        R2.state2 = R.state2 + kStateFields * cap1;
+        R2.sample_L = R.sample_L + 3 * cap1;
+        R2.seg_count = R.seg_count + (cap1 / kBlock) * PTK_MAX_DEPTH;
+        R2.split_counters = R.split_counters + kSplitCounters;
+        R2.seg_pend = R.seg_pend + cap1 / kBlock;
+        R2.pend_slot = R.pend_slot + cap1;
+        R2.pend_mask = R.pend_mask + cap1;
+        R2.pend_best = R.pend_best + 9 * cap1;
+        uint64_t first = pixel_count * kOverlapFirstPct / 100u;
+        if (first < 1) first = 1;
+        hipStream_t main_stream = c->stream;
+        PTK_HIP(c, hipEventRecord(c->fork_ev, main_stream));
+        PTK_HIP(c, hipStreamWaitEvent(c->side_stream, c->fork_ev, 0));
+        rc = render_samples_impl(c, R1, seed, pixel_begin, first, sample_begin, sample_count, sum_rgb, accumulate);
+        c->stream = c->side_stream; // (the chain launches on the context's stream)
+        const int rc2 = render_samples_impl(c, R2, seed, pixel_begin + first, pixel_count - first, sample_begin, sample_count, sum_rgb, accumulate);
+        c->stream = main_stream;
+        // the join is made whatever the chains returned: nothing may be left running beside the caller's stream
+        const hipError_t e1 = hipEventRecord(c->join_ev, c->side_stream);
+        const hipError_t e2 = hipStreamWaitEvent(main_stream, c->join_ev, 0);
+        if (rc == PTK_OK) rc = rc2;
+        if (rc == PTK_OK && (e1 != hipSuccess || e2 != hipSuccess))
+            rc = fail(c, PTK_ERR_HIP, std::string("ptk_render_samples: joining the second launch chain: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    } else {
+        rc = render_samples_impl(c, R, seed, pixel_begin, pixel_count, sample_begin, sample_count, sum_rgb, accumulate);
+    }
     c->timing_hold = false;
     if (rc == PTK_OK && !split && (c->compact == 2 || c->fuse == 2) && c->snapshot_ev && !c->snapshot_pending) {
         PTK_HIP(c, hipMemcpyAsync(c->h_snapshot, c->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -2886,6 +3003,10 @@ int ptk_ctx_set_option(ptk_ctx* c, int option, int value)
         c->kd_prune = value;
         return PTK_OK;
     }
+    if (option == PTK_OPT_OVERLAP && (value == 0 || value == 1)) {
+        c->overlap = value;
+        return PTK_OK;
+    }
     return fail(c, PTK_ERR_INVALID, "ptk_ctx_set_option: unknown option or value");
 }
 
@@ -2998,8 +3119,8 @@ int ptk_debug_stats(ptk_ctx* c, unsigned long long* out16)
     if (!c || !out16 || !c->has_scene) return PTK_ERR_INVALID;
     if (int r = set_device(c)) return r;
     PTK_HIP(c, hipStreamSynchronize(c->stream));
-    PTK_HIP(c, hipMemcpy(out16, c->S.stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    PTK_HIP(c, hipMemset(c->S.stats, 0, 32 * sizeof(unsigned long long)));
+    PTK_HIP(c, hipMemcpy(out16, c->S.stats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    PTK_HIP(c, hipMemset(c->S.stats, 0, 64 * sizeof(unsigned long long)));
     return PTK_OK;
 }
 #endif

@@ -455,6 +455,9 @@ constexpr int kKdStack = 16;    // local entries of the closed per-lane loops (k
 struct LocalStack {
     uint32_t* idx;
     float* bound;
+#ifdef PTK_STATS
+    unsigned long long* stats = nullptr;
+#endif
     __device__ __forceinline__ void put(int sp, uint32_t i, float b) const { idx[sp] = i; bound[sp] = b; }
     __device__ __forceinline__ uint32_t node(int sp) const { return idx[sp]; }
     __device__ __forceinline__ float dist(int sp) const { return bound[sp]; }
@@ -462,6 +465,9 @@ struct LocalStack {
 struct LdsStack { // entry e of lane l at [e * 64 + l]: lanes side by side, no bank conflicts
     uint32_t* idx;
     float* bound;
+#ifdef PTK_STATS
+    unsigned long long* stats = nullptr;
+#endif
     __device__ __forceinline__ void put(int sp, uint32_t i, float b) const { idx[sp * 64] = i; bound[sp * 64] = b; }
     __device__ __forceinline__ uint32_t node(int sp) const { return idx[sp * 64]; }
     __device__ __forceinline__ float dist(int sp) const { return bound[sp * 64]; }
@@ -568,7 +574,16 @@ __device__ __forceinline__ void walk_pop(KdWalk& W, const Stack& st)
     if (W.neg & kWalkSweep) {
         uint32_t i = W.cr;
         const uint32_t end = __float_as_uint(W.cs);
+#if defined(PTK_STATS) && defined(PTK_STATS_COARSE)
+        [[maybe_unused]] uint32_t sweep_iter = 0u;
+#define PTK_SWEEP_COUNT() (++sweep_iter)
+#define PTK_SWEEP_REPORT() do { atomicAdd(st.stats + 62, (unsigned long long)sweep_iter); atomicMax(st.stats + 63, (unsigned long long)sweep_iter); } while (0)
+#else
+#define PTK_SWEEP_COUNT() ((void)0)
+#define PTK_SWEEP_REPORT() ((void)0)
+#endif
         while (i < end) {
+            PTK_SWEEP_COUNT();
             const float4* __restrict__ q = reinterpret_cast<const float4*>(W.kd + i);
             const float4 h = q[0], x = q[1], y = q[2], z = q[3];
             const uint32_t a = __float_as_uint(h.x), b = __float_as_uint(h.y);
@@ -583,11 +598,13 @@ __device__ __forceinline__ void walk_pop(KdWalk& W, const Stack& st)
                 W.ca = a;
                 W.cb = b;
                 W.cr = i + 1u;
+                PTK_SWEEP_REPORT();
                 return;
             }
             i = (pass || leaf) ? i + 1u : a; // an interior node that fails takes its skip link
         }
         W.neg &= ~kWalkSweep;
+        PTK_SWEEP_REPORT();
     }
     while (W.sp > 0) {
         --W.sp;

@@ -26,7 +26,7 @@ ctx.render_begin(w, w, math.pi / 4)
 lib = _abi.load()
 lib.ptk_debug_stats.restype = C.c_int
 lib.ptk_debug_stats.argtypes = [C.c_void_p, C.c_void_p]
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 64)()
 lib.ptk_debug_stats(ctx._h, out)
 total = torch.zeros(w, w, 3, device="cuda")
 ctx.render_samples_dev(0, 0, spp, total.data_ptr())
@@ -52,4 +52,9 @@ if v[21]:
               f"refill {v[17]/wv:.0f}; fin/start {v[19]/wv:.0f}")
         if os.environ.get("PTK_STATS_COARSE"):
             print(f"  (coarse build) of the refill: {v[22]/wv:.0f} clocks in {v[23]/wv:.1f} grabs per wave ({v[22]/max(1,v[23]):.0f} per grab)")
+            for b in range(5):
+                if v[40 + b]:
+                    print(f"  bounce {b}: {v[40+b]} waves, mean {v[32+b]/v[40+b]:.0f} clocks, slowest {v[48+b]} ({v[48+b]*v[40+b]/max(1,v[32+b]):.2f} x mean); longest drain {v[57+b]}")
+            print(f"  stackless sweeps: {v[62]} node visits in all, longest single sweep call {v[63]}")
+            print(f"  drain (dry -> end) mean {v[56]/max(1,sum(v[40:45])):.0f} clocks")
 ctx.close()

@@ -398,3 +398,35 @@ def test_fused_bounces_change_nothing(_gpu_ctx_session, name):
         assert np.array_equal(out[key][0], ref_img), key
         assert out[key][1] == ref_counts, key
     assert np.array_equal(out[(2, 0, 4)][0], out[(0, 0, 4)][0]) and out[(2, 0, 4)][1] == out[(0, 0, 4)][1]
+
+
+def test_two_overlapped_chains_change_nothing(_gpu_ctx_session):
+    """PTK_OPT_OVERLAP: a split-mode call of 2^20 paths or more goes out as two launch chains (the two halves of its
+    pixel range, half of the buffers each, the second on the context's side stream between a fork and a join event).
+    A pixel's samples stay in one chain in the same order, so sums and counters are bit-identical to one chain; the
+    caller's stream order holds (the image is read on the context's stream right behind the call).  Odd pixel
+    counts, a call in several chunks (max_paths below the call's size) and an accumulating second call included."""
+    import torch
+    from pathtracing_amd import _abi
+    ctx = _gpu_ctx_session
+    ctx.set_option(_abi.PTK_OPT_SPLIT, 2)
+    ctx.upload(get_scene("mario"))
+    w, h, spp = 67, 33, 512   # 1.13 M paths per call
+    out = {}
+    try:
+        for overlap, max_paths in ((0, 0), (1, 0), (1, 300000), (0, 300000)):
+            ctx.set_option(_abi.PTK_OPT_OVERLAP, overlap)
+            ctx.render_begin(w, h, FOV, max_paths=max_paths)
+            ctx.reset_counters()
+            total = torch.zeros(h, w, 3, device="cuda")
+            ctx.render_samples_dev(5, 0, spp, total.data_ptr())
+            ctx.render_samples_dev(5, spp, spp, total.data_ptr(), accumulate=True, pixel_begin=7, pixel_count=w * h - 10)
+            ctx.synchronize()
+            out[(overlap, max_paths)] = (total.cpu().numpy(), ctx.counters())
+    finally:
+        ctx.set_option(_abi.PTK_OPT_OVERLAP, 1)
+    ref_img, ref_counts = out[(0, 0)]
+    assert ref_counts[0] == w * h * spp + (w * h - 10) * spp and np.all(np.isfinite(ref_img)) and ref_img.max() > 0
+    for key in ((1, 0), (1, 300000), (0, 300000)):
+        assert np.array_equal(out[key][0], ref_img), key
+        assert out[key][1] == ref_counts, key

@@ -49,17 +49,14 @@ constexpr uint64_t kNoallocWordsPerPath = 13 + 13 + 3 + 1 + 2 + 9; // two queues
 #ifndef PTK_OVERLAP_MIN_PATHS
 #define PTK_OVERLAP_MIN_PATHS (1ull << 20)
 #endif
+#ifndef PTK_WALK_BLOCK
+#define PTK_WALK_BLOCK 64
+#endif
 #ifndef PTK_OVERLAP_FIRST_PCT
 #define PTK_OVERLAP_FIRST_PCT 50
 #endif
 #ifndef PTK_OVERLAP_WALK_BLOCKS
 #define PTK_OVERLAP_WALK_BLOCKS 0
-#endif
-#ifndef PTK_DRAIN_FIN
-#define PTK_DRAIN_FIN 0
-#endif
-#ifndef PTK_DRAIN_LANES
-#define PTK_DRAIN_LANES 0
 #endif
 #ifndef PTK_WALK_UNIT
 #define PTK_WALK_UNIT 64u
@@ -82,6 +79,9 @@ static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
 namespace {
 
 constexpr int kBlock = 256;          // one queue segment = one workgroup = 4 waves
+constexpr int kWalkBlock = PTK_WALK_BLOCK; // workgroup of the persistent walker: its waves share nothing, and a one-wave workgroup
+                                           // hands its registers and LDS back the moment its wave ends (with PTK_OPT_OVERLAP the
+                                           // other chain's workgroups move in: Mario +2 % over 256)
 // The split-mode kernels (k_bounce_split, k_walk_plan, k_walk, k_shade_parked, k_batch_parked) hand out a segment's
 // parked rays in quarters of 64 (unit = segment * 4 + quarter) and scan four wave counts per workgroup; the bounce
 // kernels' LDS budget (WaveLds) is sized for four waves per workgroup.  Another segment size needs those revisited.
@@ -628,10 +628,10 @@ constexpr uint32_t kRefillIdle = PTK_REFILL_IDLE; // idle lanes that trigger a r
 constexpr uint32_t kWalkMin = PTK_WALK_MIN;       // walking lanes below which the walk loop yields to the refill
 
 template <bool BATCH>
-__global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32_t bounce_in, const SplitBufs Q, const BatchIO B)
+__global__ __launch_bounds__(kWalkBlock, 4) void k_walk(const DScene S, const uint32_t bounce_in, const SplitBufs Q, const BatchIO B)
 {
     enum : uint32_t { IDLE = 0u, START = 1u, WALK = 2u, FIN = 3u, DONE = 4u };
-    __shared__ WalkLds wave_lds[kBlock / 64];
+    __shared__ WalkLds wave_lds[kWalkBlock / 64];
     const uint32_t lane = lane_id();
     const uint32_t bounce = BATCH ? 0u : bounce_in;
     const uint32_t nunits = Q.num_segments * kWalkUnitsPerSegment; // work units: kWalkUnit slots of a segment's parked list
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
     // instead, each head on a cache line of its own, and a wave starts at the head of its workgroup's number and moves on
     // to the next head when one runs dry: after kWalkHeads dry heads the lists are empty.
     const uint32_t nchunks = (nunits + walk_chunk - 1u) / walk_chunk;
-    uint32_t head = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) % kWalkHeads, heads_dry = 0u;
+    uint32_t head = (blockIdx.x * (kWalkBlock / 64) + (threadIdx.x >> 6)) % kWalkHeads, heads_dry = 0u;
     uint32_t* __restrict__ const heads = Q.walk_head + bounce * kWalkHeads * kWalkHeadStride;
 
     WalkLds& my_lds = wave_lds[threadIdx.x >> 6];
@@ -791,29 +791,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_walk(const DScene S, const uint32
             const uint32_t n_pop = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_pop));
             const uint32_t n_walk = n_node + n_leaf + n_pop;
             if (n_walk < walk_min || n_walk == 0u) break;
-#if PTK_DRAIN_FIN
-            // the lists are dry: a lane whose walk has just ended goes on to its next tree at once instead of waiting for the
-            // wave's last walk
-            if (dry && __builtin_amdgcn_ballot_w64(state == FIN) != 0ull) break;
-#endif
-#if PTK_DRAIN_LANES
-            // Dry lists and a few rays left: the wave is waiting for memory, not for instructions, and every pass that serves
-            // one place only leaves the rays in the other two standing.  One pass then serves all three, in the order in
-            // which a ray moves through them (leaf -> pop -> descend).
-            if (dry && n_walk <= PTK_DRAIN_LANES) {
-                if (n_leaf != 0u) {
-                    walk_leaf_stage(W, S, at_leaf, my_lds);
-                    if (at_leaf && W.leaf_done >= (W.cb & kKdCountMask)) {
-                        W.leaf_done = 0u;
-                        W.cur = kWalkPop;
-                    }
-                }
-                if (state == WALK && W.cur == kWalkPop) walk_pop(W, stack);
-                if (state == WALK && W.cur != kWalkNone && W.cur != kWalkPop && (W.cb & kKdCountMask) == 0u)
-                    walk_descend_step<true>(W, S, stack, stack_cap);
-                continue;
-            }
-#endif
             // lanes served per instruction spent: a descend step costs about 135 VALU instructions, a pop 90,
             // a leaf stage 250 or more
             if (2u * n_node >= n_leaf && 2u * n_node >= 3u * n_pop) {
@@ -1770,7 +1747,7 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
                                                             Q.walk_head + kWalkPlanBase + b);
                     {
                         LaunchTimer lt(c, PTK_KERNEL_WALK);
-                        k_walk<false><<<dim3(wb), block, 0, c->stream>>>(c->S, b, Q, BatchIO{});
+                        k_walk<false><<<dim3(wb * (kBlock / kWalkBlock)), dim3(kWalkBlock), 0, c->stream>>>(c->S, b, Q, BatchIO{});
                     }
                     LaunchTimer lt(c, PTK_KERNEL_SHADE_PARKED);
                     k_shade_parked<<<grid, block, 0, c->stream>>>(c->S, A, Q);
@@ -2470,7 +2447,7 @@ int ptk_intersect_batch_dev(ptk_ctx* c, uint64_t n, const float* o, const float*
         k_intersect_batch_split<<<g, b, 0, c->stream>>>(c->S, B, Q);
         const uint32_t wb = blocks < kWalkBlocks ? blocks : kWalkBlocks;
         k_walk_plan<<<1, 1024, 0, c->stream>>>(Q.seg_pend, Q.num_segments, Q.walk_chunk, wb * (kBlock / 64), Q.walk_head + kWalkPlanBase);
-        k_walk<true><<<dim3(wb), b, 0, c->stream>>>(c->S, 0u, Q, B);
+        k_walk<true><<<dim3(wb * (kBlock / kWalkBlock)), dim3(kWalkBlock), 0, c->stream>>>(c->S, 0u, Q, B);
         k_batch_parked<<<g, b, 0, c->stream>>>(c->S, B, Q);
     } else {
         LaunchTimer lt(c, PTK_KERNEL_INTERSECT_BATCH);

@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--compact", type=int, default=None, help="PTK_OPT_COMPACT override (0/1/2), for A/B runs")
     ap.add_argument("--fuse", type=int, default=None, help="PTK_OPT_FUSE override (0/1/2), for A/B runs")
     ap.add_argument("--overlap", type=int, default=None, help="PTK_OPT_OVERLAP override (0/1), for A/B runs and profiles")
+    ap.add_argument("--walk-stack", type=int, default=None, help="PTK_OPT_WALK_STACK override (entries of the walker's short stack), for A/B runs")
     ap.add_argument("--no-timing", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 path on a box with ONE GPU: every rank uses cuda:0 and the HDR sum "
@@ -213,6 +214,8 @@ def main():
         ctx.set_option(9, args.fuse)
     if args.overlap is not None:
         ctx.set_option(10, args.overlap)
+    if args.walk_stack is not None:
+        ctx.set_option(7, args.walk_stack)
     t_up = time.perf_counter()
     ctx.upload(scene)
     torch.cuda.synchronize(dev)

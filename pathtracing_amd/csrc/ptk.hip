@@ -833,8 +833,8 @@ __global__ __launch_bounds__(kWalkBlock, 4) void k_walk(const DScene S, const ui
     PTK_STAT(S, 15, acc_l);
     PTK_STAT(S, 17, acc_r);
     PTK_STAT(S, 19, acc_f);
-    PTK_STAT(S, 22, acc_a);
-    PTK_STAT(S, 23, acc_n);
+    PTK_STAT(S, 37, acc_a); // (22 / 23 are the descend passes' counters)
+    PTK_STAT(S, 38, acc_n);
     PTK_STAT(S, 20, PTK_CLOCK() - clk_begin);
     PTK_STAT(S, 21, 1);
 #if defined(PTK_STATS) && defined(PTK_STATS_COARSE)

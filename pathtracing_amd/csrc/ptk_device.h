@@ -236,6 +236,46 @@ __device__ __forceinline__ V3 sh_mat_dir(const float* __restrict__ m, V3 p)
 // sinf and cosf, which differ from the host libm's in the last place just the same.  (Since round 2 the
 // shading normalisations use the 1-ulp hardware rsq / sqrt as well, see the sh_* helpers above; hit decisions
 // never do.)
+// atan2 and asin for the equirectangular background lookup (sampler.cpp:116-124): shading arithmetic, never a hit decision.
+// atan(a) on [0, 1] as a * P(a^2) (degree 7 in a^2, near-minimax: 1.9e-7 rad in fp32), the octant folded back afterwards;
+// asin(x) on [0, 1] as pi/2 - sqrt(1 - x) Q(x) (degree 7: 2.9e-7 rad).  The map coordinate u = atan2 / 2 pi therefore sits
+// within 3e-8 of the exact one and v = asin / pi within 1e-7, less than an ulp of a coordinate near 1; the library routines
+// (correctly rounded divides included) cost about four times the instructions.
+__device__ __forceinline__ float sh_atan2(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float a = mn * __builtin_amdgcn_rcpf(mx);
+    a = mx > 0.0f ? a : 0.0f; // atan2(0, 0) = 0
+    const float s = a * a;
+    float p = -0.004668773151934147f;
+    p = __builtin_fmaf(p, s, 0.02416618913412094f);
+    p = __builtin_fmaf(p, s, -0.0593671016395092f);
+    p = __builtin_fmaf(p, s, 0.09906096756458282f);
+    p = __builtin_fmaf(p, s, -0.14016585052013397f);
+    p = __builtin_fmaf(p, s, 0.19969235360622406f);
+    p = __builtin_fmaf(p, s, -0.33331960439682007f);
+    p = __builtin_fmaf(p, s, 0.9999998807907104f);
+    float r = p * a;
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.0f ? 3.14159265358979323846f - r : r;
+    return __builtin_copysignf(r, y);
+}
+__device__ __forceinline__ float sh_asin(float x)
+{
+    const float ax = fabsf(x);
+    float p = -0.0012370048789307475f;
+    p = __builtin_fmaf(p, ax, 0.006580885034054518f);
+    p = __builtin_fmaf(p, ax, -0.01696547120809555f);
+    p = __builtin_fmaf(p, ax, 0.030808253213763237f);
+    p = __builtin_fmaf(p, ax, -0.05014502629637718f);
+    p = __builtin_fmaf(p, ax, 0.08897409588098526f);
+    p = __builtin_fmaf(p, ax, -0.21459849178791046f);
+    p = __builtin_fmaf(p, ax, 1.570796251296997f);
+    const float r = __builtin_fmaf(-__builtin_amdgcn_sqrtf(fmaxf(1.0f - ax, 0.0f)), p, 1.57079632679489661923f);
+    return __builtin_copysignf(r, x);
+}
+
 __device__ __forceinline__ void sincos_2pi_shade(float u, float& s, float& c)
 {
     // u in [0, 1): quarter turns q = round(4u) in {0..4}, r = 2 pi u - q pi/2 in [-pi/4, pi/4]
@@ -1868,9 +1908,15 @@ __device__ __forceinline__ V3 sampler_sample(const DScene& S, const DSampler sd,
 __device__ __forceinline__ V3 background_sample(const DScene& S, V3 dir)
 {
     if (S.bg_kind == PTK_BACKGROUND_COLOR) return mk(S.bg_r, S.bg_g, S.bg_b);
+#ifdef PTK_BG_LIBM // the library's atan2f / asinf and correctly rounded divides, for A/B runs
     const V3 n = normalize(dir);
     const float u = atan2f(n.x, n.z) / (2.0f * 3.14159265358979323846f) + 0.5f;
     const float v = asinf(n.y) / 3.14159265358979323846f - 0.5f;
+#else
+    const V3 n = sh_normalize(dir);
+    const float u = __builtin_fmaf(sh_atan2(n.x, n.z), 0.15915494309189533577f, 0.5f);
+    const float v = __builtin_fmaf(sh_asin(n.y), 0.31830988618379067154f, -0.5f);
+#endif
     return image_sample(S.textures[S.bg_texture], S.bg_mode, u, v);
 }
 

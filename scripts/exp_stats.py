@@ -51,7 +51,7 @@ if v[21]:
               f"pop {v[14]/wv:.0f} ({v[14]/max(1,v[29]):.0f} per pass); leaf {v[15]/wv:.0f} ({v[15]/max(1,v[26]):.0f} per stage); "
               f"refill {v[17]/wv:.0f}; fin/start {v[19]/wv:.0f}")
         if os.environ.get("PTK_STATS_COARSE"):
-            print(f"  (coarse build) of the refill: {v[22]/wv:.0f} clocks in {v[23]/wv:.1f} grabs per wave ({v[22]/max(1,v[23]):.0f} per grab)")
+            print(f"  (coarse build) of the refill: {v[37]/wv:.0f} clocks in {v[38]/wv:.1f} grabs per wave ({v[37]/max(1,v[38]):.0f} per grab)")
             for b in range(5):
                 if v[40 + b]:
                     print(f"  bounce {b}: {v[40+b]} waves, mean {v[32+b]/v[40+b]:.0f} clocks, slowest {v[48+b]} ({v[48+b]*v[40+b]/max(1,v[32+b]):.2f} x mean); longest drain {v[57+b]}")

@@ -204,8 +204,15 @@ __device__ __forceinline__ void shade_hit(const DScene& S, const Hit& h, V3 d, f
 // pathtracer::trace_recursive for one cast (pathtracer.cpp:29-68) in throughput form: updates L, and
 // for a hit before the last bounce turns (o, d, T) into the next ray.  Returns whether the path goes
 // on; a path that ends (miss, depth 5, zero throughput) writes its radiance to sample_L[path].
+// RNG: a Philox block holds the draws of two consecutive dimension pairs (rng_pair).  A kernel that keeps a path over
+// several bounces (k_bounce_fused) hands in the second half of the block it drew last (`carry`) and gets the second half
+// of a newly drawn block back: three blocks per path instead of five.  The values are the same either way.
+struct RngCarry {
+    uint32_t z, w;
+};
+template <bool CARRY = false>
 __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, const uint32_t bounce, const Hit& h, V3& o, V3& d,
-                                          V3& T, V3& L, uint32_t path)
+                                          V3& T, V3& L, uint32_t path, RngCarry* carry = nullptr)
 {
     bool alive = false;
     if (h.node < 0) {
@@ -218,7 +225,23 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
         if (bounce + 1 < PTK_MAX_DEPTH) {
             const uint32_t pl = path / A.samples;
             const uint32_t sm = path - pl * A.samples;
-            rng_pair(A.seed, (uint32_t)(A.pixel_begin + pl), A.sample_begin + sm, 1u + bounce, u1, u2);
+            if (CARRY) {
+                const uint32_t j = 1u + bounce; // wave-uniform in the kernels that carry
+                if (j & 1u) {
+                    u1 = u01(carry->z);
+                    u2 = u01(carry->w);
+                } else {
+                    const uint64_t sample = A.sample_begin + sm;
+                    const uint4 r = philox4x32_10((uint32_t)(A.pixel_begin + pl), (uint32_t)sample, (uint32_t)(sample >> 32), j >> 1,
+                                                  (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                    u1 = u01(r.x);
+                    u2 = u01(r.y);
+                    carry->z = r.z;
+                    carry->w = r.w;
+                }
+            } else {
+                rng_pair(A.seed, (uint32_t)(A.pixel_begin + pl), A.sample_begin + sm, 1u + bounce, u1, u2);
+            }
         }
         V3 n;
         float uvx, uvy, uu, vv;
@@ -257,13 +280,23 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const BounceArgs& A, 
 }
 
 // abstract_pathtracer.cpp:74-83: the jittered camera ray of path `path` of the chunk
-__device__ __forceinline__ void primary_ray(const DScene& S, const DView& V, const BounceArgs& A, uint32_t path, V3& o, V3& d)
+__device__ __forceinline__ void primary_ray(const DScene& S, const DView& V, const BounceArgs& A, uint32_t path, V3& o, V3& d,
+                                            RngCarry* carry = nullptr)
 {
     const uint32_t pl = path / A.samples;
     const uint32_t sm = path - pl * A.samples;
     const uint32_t pixel = (uint32_t)(A.pixel_begin + pl);
     float u1, u2;
-    rng_pair(A.seed, pixel, A.sample_begin + sm, 0u, u1, u2);
+    if (carry) { // block 0: the jitter, and bounce 0's hemisphere draw for the caller to keep
+        const uint64_t sample = A.sample_begin + sm;
+        const uint4 r = philox4x32_10(pixel, (uint32_t)sample, (uint32_t)(sample >> 32), 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        u1 = u01(r.x);
+        u2 = u01(r.y);
+        carry->z = r.z;
+        carry->w = r.w;
+    } else {
+        rng_pair(A.seed, pixel, A.sample_begin + sm, 0u, u1, u2);
+    }
     o = mk(S.cam_x, S.cam_y, S.cam_z);
     d = primary_dir(V, pixel % V.width, pixel / V.width, u1, u2);
 }
@@ -395,11 +428,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce_fused(const DScene S, cons
         bool on = tid < cnt;
         const uint32_t path = base + tid;
         V3 o, d, T = mk(1.0f, 1.0f, 1.0f), L = mk(0.0f, 0.0f, 0.0f);
-        primary_ray(S, V, A, on ? path : base, o, d);
+        RngCarry carry;
+        primary_ray(S, V, A, on ? path : base, o, d, &carry);
         {
             Hit h;
             intersect_scene_mode<MODE, true>(S, o, d, on, h, lds);
-            if (on) on = shade_ray(S, A, 0u, h, o, d, T, L, path);
+            if (on) on = shade_ray<true>(S, A, 0u, h, o, d, T, L, path, &carry);
         }
 #pragma unroll 1
         for (uint32_t b = 1u; b < PTK_MAX_DEPTH; ++b) {
@@ -408,7 +442,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce_fused(const DScene S, cons
             rays += (uint32_t)__popcll(live);
             Hit h;
             intersect_scene_mode<MODE, false>(S, o, d, on, h, lds);
-            if (on) on = shade_ray(S, A, b, h, o, d, T, L, path);
+            if (on) on = shade_ray<true>(S, A, b, h, o, d, T, L, path, &carry);
         }
     }
     if ((tid & 63u) == 0u) A.seg_count[(size_t)(1u + (tid >> 6)) * A.num_segments + seg] = rays;

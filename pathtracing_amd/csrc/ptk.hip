@@ -340,10 +340,11 @@ __global__ __launch_bounds__(kBlock, (MODE & 2) ? 1 : 4) void k_bounce(const DSc
     V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f), T = o, L = o;
     uint32_t path = 0u;
     bool alive = false;
+    [[maybe_unused]] RngCarry carry{ 0u, 0u };
     if (wave_live) {
         if (FIRST) {
             path = slot;
-            primary_ray(S, V, A, path, o, d);
+            primary_ray(S, V, A, path, o, d, &carry); // block 0 also holds bounce 0's hemisphere draw
             T = mk(1.0f, 1.0f, 1.0f);
             L = mk(0.0f, 0.0f, 0.0f);
         } else {
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(kBlock, (MODE & 2) ? 1 : 4) void k_bounce(const DSc
             }
         } else
 #endif
-        if (on) alive = shade_ray(S, A, A.bounce, h, o, d, T, L, path);
+        if (on) alive = FIRST ? shade_ray<true>(S, A, 0u, h, o, d, T, L, path, &carry) : shade_ray(S, A, A.bounce, h, o, d, T, L, path);
     }
 
     PTK_STAT(S, 12, PTK_CLOCK() - kc0);
@@ -552,9 +553,10 @@ __global__ __launch_bounds__(kBlock) void k_bounce_split(const DScene S, const D
 
     V3 o, d, T, L;
     uint32_t path;
+    [[maybe_unused]] RngCarry carry{ 0u, 0u };
     if (FIRST) {
         path = slot;
-        primary_ray(S, V, A, path, o, d);
+        primary_ray(S, V, A, path, o, d, &carry);
         T = mk(1.0f, 1.0f, 1.0f);
         L = mk(0.0f, 0.0f, 0.0f);
     } else {
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_split(const DScene S, const D
     // bounce 0 has no input queue: the walker reads the generated ray from queue 0
     if (FIRST && parked) queue_store(Q.q[0], cap, slot, o, d, T, L, path);
     bool alive = false;
-    if (on && !parked) alive = shade_ray(S, A, A.bounce, h, o, d, T, L, path);
+    if (on && !parked) alive = FIRST ? shade_ray<true>(S, A, 0u, h, o, d, T, L, path, &carry) : shade_ray(S, A, A.bounce, h, o, d, T, L, path);
 
     // parked rays and survivors are packed inside the segment (no global atomics, as in k_bounce)
     uint32_t park_rank, alive_rank, park_off, park_total, alive_off, alive_total;

@@ -585,6 +585,21 @@ __device__ __forceinline__ bool slab_certified(float t7, float t8, bool& certain
     return t7 <= t8 && t8 >= 0.0f;
 }
 
+// v_max_f32 / v_min_f32 as they are (maxNum / minNum: a NaN operand yields the other one), without the compiler's quieting
+// of operands it cannot prove canonical
+__device__ __forceinline__ float raw_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float raw_min(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // (re)starts at node `idx`: header words + entry / exit distances from its own cut box
 __device__ __forceinline__ void walk_enter(KdWalk& W, uint32_t idx)
 {
@@ -724,19 +739,23 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
     const bool down = ((W.neg >> k) & 1u) != 0u; // d[k] < 0
     // (every select below picks between computed values)
     const float ex = W.ex, ey = W.ey, ez = W.ez, xx = W.xx, xy = W.xy, xz = W.xz;
-    const float e_yz = fmaxf(ey, ez), e_xz = fmaxf(ex, ez), e_xy = fmaxf(ex, ey);
-    const float x_yz = fminf(xy, xz), x_xz = fminf(xx, xz), x_xy = fminf(xx, xy);
+    // (raw_max / raw_min: the six distances come through selects and loop-carried registers, where the compiler no longer
+    // knows them to be canonical and would put a quieting v_max x, x in front of every fminf / fmaxf)
+    const float e_yz = raw_max(ey, ez), e_xz = raw_max(ex, ez), e_xy = raw_max(ex, ey);
+    const float x_yz = raw_min(xy, xz), x_xz = raw_min(xx, xz), x_xy = raw_min(xx, xy);
     const float e12 = k == 0u ? e_yz : (k == 1u ? e_xz : e_xy); // entry / exit of the two other axes together
     const float x12 = k == 0u ? x_yz : (k == 1u ? x_xz : x_xy);
-    const float e_all = fmaxf(e_yz, ex), x_all = fminf(x_yz, xx); // the node's own box
+    const float e_all = raw_max(e_yz, ex), x_all = raw_min(x_yz, xx); // the node's own box
     // one child has its ENTRY on axis k moved to the cut, the other its EXIT
-    const float a7 = fmaxf(e12, ts), a8 = x_all; // entry moved
-    const float b7 = e_all, b8 = fminf(x12, ts); // exit moved
-    bool ca_, cb_;
-    const bool a_in = slab_certified(a7, a8, ca_);
-    const bool b_in = slab_certified(b7, b8, cb_);
-    bool bl_in = down ? a_in : b_in, br_in = down ? b_in : a_in;
-    const bool cl = down ? ca_ : cb_, cr_ = down ? cb_ : ca_;
+    const float a7 = raw_max(e12, ts), a8 = x_all; // entry moved
+    const float b7 = e_all, b8 = raw_min(x12, ts); // exit moved
+    // left / right picked as distances, before the decisions (a select between two decisions costs four instructions: the
+    // compiler turns each into a 0 / 1 register and back)
+    const float l7 = down ? a7 : b7, l8 = down ? a8 : b8;
+    const float r7 = down ? b7 : a7, r8 = down ? b8 : a8;
+    bool cl, cr_;
+    bool bl_in = slab_certified(l7, l8, cl);
+    bool br_in = slab_certified(r7, r8, cr_);
     const bool exact_only = (W.neg & kWalkExact) != 0u;
     const bool redo_l = has_l && (!cl || exact_only), redo_r = has_r && (!cr_ || exact_only);
     if (__builtin_amdgcn_ballot_w64(redo_l || redo_r) != 0ull) { // rare: the reference's own six divides on the child's own box
@@ -754,6 +773,26 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
     const bool er = has_r && br_in && !kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
     const bool right_first = ((W.neg >> k) & 1u) != 0u;
     const bool take_r = er && (right_first || !el);
+    if constexpr (DEFER_POP) {
+        // The walker kernel's form: every field of the state is written once, at the end, as a select (as nested branches,
+        // below, each path defines its own version of the state and the compiler joins them with more register copies).
+        const bool both = el && er;
+        const bool over = both && W.sp >= cap; // short stack full: sweep this node's subtree [cur + 1, ca) instead (see kWalkStack)
+        const bool go = (el || er) && !over;
+        if (both && !over) st.put(W.sp, take_r ? li : ri, take_r ? bl : br);
+        W.sp += (both && !over) ? 1 : 0;
+        const bool entry_moved = take_r != down; // the child taken: left has its entry moved when the ray runs down, right when up
+        W.cur = go ? (take_r ? ri : li) : kWalkPop;
+        W.ca = go ? __float_as_uint(take_r ? rh.x : lh.x) : W.ca;
+        W.cb = go ? __float_as_uint(take_r ? rh.y : lh.y) : W.cb;
+        W.cr = go ? __float_as_uint(take_r ? rh.z : lh.z) : (over ? li : W.cr);
+        W.cs = go ? (take_r ? rh.w : lh.w) : (over ? __uint_as_float(ca) : W.cs);
+        W.neg |= over ? kWalkSweep : 0u;
+        W.ex = (go && k == 0u && entry_moved) ? ts : ex; W.xx = (go && k == 0u && !entry_moved) ? ts : xx;
+        W.ey = (go && k == 1u && entry_moved) ? ts : ey; W.xy = (go && k == 1u && !entry_moved) ? ts : xy;
+        W.ez = (go && k == 2u && entry_moved) ? ts : ez; W.xz = (go && k == 2u && !entry_moved) ? ts : xz;
+        return;
+    }
     if (el && er && W.sp >= cap) {
         // short stack full: no ordering below this node, sweep its subtree [cur + 1, ca) instead (see kWalkStack)
         W.neg |= kWalkSweep;

@@ -407,6 +407,35 @@ __device__ __forceinline__ bool tri_eval(const float4 q0, const float4 q1, const
     return false;
 }
 
+// The same without early returns, for callers that test a triangle per lane with the whole wave (the walker's pooled leaf
+// stage): every lane runs every operation anyway, and as compiled the three nested exits of tri_eval cost an exec-mask region
+// each plus a fresh set of zeroed result registers per level (about thirty moves per call).  Same operations in the same
+// order, so a lane that hits gets the same values; the decision is the conjunction of the same comparisons (a NaN distance
+// or cosine passes its test in both forms and fails the barycentric ones).
+__device__ __forceinline__ bool tri_eval_flat(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 o,
+                                              V3 d, float& dd_out, V3& bar_out, V3& p_out)
+{
+    const V3 v0 = mk(q0.x, q0.y, q0.z);
+    const V3 N = mk(q0.w, q1.x, q1.y);
+    const V3 l = o - v0;
+    const float distance = dot(l, N);
+    const float cosine = dot(d, N);
+    const V3 projection = o + d * (distance / -cosine);
+    const V3 e0 = mk(q1.z, q1.w, q2.x);
+    const V3 e1 = mk(q2.y, q2.z, q2.w);
+    const V3 v2 = projection - v0;
+    const float d20 = dot(v2, e0);
+    const float d21 = dot(v2, e1);
+    const float v = (q3.z * d20 - q3.y * d21) * q3.w;
+    const float w = (q3.x * d21 - q3.y * d20) * q3.w;
+    const float u = 1.0f - v - w;
+    const V3 dv = o - projection;
+    dd_out = dot(dv, dv);
+    bar_out = mk(u, v, w);
+    p_out = projection;
+    return !(distance < 0) && !(cosine >= 0) && (u >= 0 && v >= 0 && w >= 0);
+}
+
 // tri_eval plus the bookkeeping of intersect_internal (scene.cpp:196-202).  Returns true
 // and updates (best_d, best_slot, bar, p) when this triangle is hit and strictly closer,
 // or exactly as close but earlier in the reference's visiting order (`slot` = position in
@@ -1802,8 +1831,8 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
         const uint32_t slot = c_first + (valid ? t - c_start : 0u);
         const float4* tp = S.tri_hit + (size_t)slot * 4;
         const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
-        float dd = 0.0f;
-        V3 bar = mk(0.0f, 0.0f, 0.0f), p = mk(0.0f, 0.0f, 0.0f);
+        float dd;
+        V3 bar, p;
         PTK_STAT_FINE(S, 18, 1);
 #ifdef PTK_STATS
         { // how many items the two side tests of scene.cpp:149,158 alone would reject
@@ -1813,7 +1842,8 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
             PTK_STAT_FINE(S, 31, __popcll(so));
         }
 #endif
-        const bool hit = valid && tri_eval(q0, q1, q2, q3, co, cd, dd, bar, p) && dd < 3.402823466e+38f;
+        const bool tri_hit = tri_eval_flat(q0, q1, q2, q3, co, cd, dd, bar, p);
+        const bool hit = valid && tri_hit && dd < 3.402823466e+38f;
         const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | slot;
         if (hit) atomicMin(&L.key[c], key);
         wave_sync();

@@ -822,9 +822,13 @@ __global__ __launch_bounds__(kWalkBlock, 4) void k_walk(const DScene S, const ui
             const bool at_pop = walking && W.cur == kWalkPop;
             const bool at_leaf = walking && !at_pop && (W.cb & kKdCountMask) != 0u;
             const bool at_node = walking && !at_pop && !at_leaf;
-            const uint32_t n_node = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_node));
-            const uint32_t n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_leaf));
-            const uint32_t n_pop = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(at_pop));
+            // (the three head counts from the ballots of the plain compares, combined as 64-bit masks: a ballot of a derived
+            // condition is compiled as condition -> 0 / 1 register -> compare)
+            const uint64_t m_walk = __builtin_amdgcn_ballot_w64(walking), m_cpop = __builtin_amdgcn_ballot_w64(W.cur == kWalkPop);
+            const uint64_t m_cleaf = __builtin_amdgcn_ballot_w64((W.cb & kKdCountMask) != 0u);
+            const uint32_t n_node = (uint32_t)__popcll(m_walk & ~m_cpop & ~m_cleaf);
+            const uint32_t n_leaf = (uint32_t)__popcll(m_walk & ~m_cpop & m_cleaf);
+            const uint32_t n_pop = (uint32_t)__popcll(m_walk & m_cpop);
             const uint32_t n_walk = n_node + n_leaf + n_pop;
             if (n_walk < walk_min || n_walk == 0u) break;
             // lanes served per instruction spent: a descend step costs about 135 VALU instructions, a pop 90,

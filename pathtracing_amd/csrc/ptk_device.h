@@ -1106,6 +1106,10 @@ __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, 
                 behind = t_out < 0.0f;
             }
             const uint32_t bit = (lane_on && !(missed || behind)) ? (1u << (n - g)) : 0u;
+            if (BALLS) { // every node is a sphere: no routing by class (as compiled, eight selects per node)
+                pend_sphere |= bit;
+                continue;
+            }
             const uint32_t cls = nd->cls; // wave-uniform
             if (cls == kClassSphere) pend_sphere |= bit;
             else if (cls == kClassSmallLeaf) pend_small |= bit;

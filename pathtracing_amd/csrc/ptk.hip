@@ -1820,7 +1820,8 @@ int render_samples_impl(ptk_ctx* c, const RenderBufs& R, uint64_t seed, uint64_t
             if (R.fused && !A.dense && kernel_mode(c, true) == 8 && kernel_mode(c, false) == 8) {
                 {
                     LaunchTimer lt(c, PTK_KERNEL_BOUNCE_FUSED);
-                    k_bounce_fused<8><<<grid, block, 0, c->stream>>>(c->S, c->V, A);
+                    if (c->num_trees == 0u) k_bounce_fused<40><<<grid, block, 0, c->stream>>>(c->S, c->V, A); // no KD walk in the kernel
+                    else k_bounce_fused<8><<<grid, block, 0, c->stream>>>(c->S, c->V, A);
                 }
                 const uint32_t acc_blocks = (uint32_t)((np * 64 + kBlock - 1) / kBlock);
                 {

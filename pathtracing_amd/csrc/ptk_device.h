@@ -1379,7 +1379,8 @@ __device__ __forceinline__ void tri_eval2(const float4 r0, const float4 r1, cons
 // mask over DScene::tree_nodes (at most 64 of them) for the walker kernel (k_walk in ptk.hip).
 // BUNDLE: the wave's rays are expected to be nearly the same ray (primary rays: a wave holds 64 samples
 // of one pixel), so the cull loop only visits the nodes that the bundle as a whole can touch (below).
-template <bool PRUNE, bool SPLIT, bool BUNDLE = false>
+// NO_TREES: the scene has no node of class kClassTree (spheres and one-leaf meshes only), so the KD walk drops out of stage 2.
+template <bool PRUNE, bool SPLIT, bool BUNDLE = false, bool NO_TREES = false>
 __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best,
                                                          WaveLds& L, unsigned long long& tree_mask)
 {
@@ -1551,8 +1552,8 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
                 a = sp;
             }
         }
-        const bool is_tree = !SPLIT && have && cls == kClassTree;
-        if (!SPLIT && __builtin_amdgcn_ballot_w64(is_tree) != 0ull) {
+        const bool is_tree = !SPLIT && !NO_TREES && have && cls == kClassTree;
+        if (!SPLIT && !NO_TREES && __builtin_amdgcn_ballot_w64(is_tree) != 0ull) {
             const DMesh mesh = S.meshes[is_tree ? nd->mesh : 0u];
             int tprim = -1;
             V3 tb = mk(0.0f, 0.0f, 0.0f), tp = mk(0.0f, 0.0f, 0.0f);
@@ -1879,13 +1880,14 @@ __device__ __forceinline__ void walk_leaf_stage(KdWalk& W, const DScene& S, bool
 // MODE bit 4 (with bits 0 and 2): every node is a sphere with a bounding ball, culled against that (intersect_scene_lanelist).
 // MODE bit 0: per-lane lists instead of the all-lanes-every-node loop (PTK_OPT_TRAVERSAL), bit 1: pruned KD
 // walk (PTK_OPT_KD_PRUNE), bit 2 (with bit 0): candidate lists after the conservative cull (PTK_OPT_NODE_CULL),
-// bit 3: wave-balanced work lists (PTK_OPT_BALANCE; needs the wave's WaveLds).
+// bit 3: wave-balanced work lists (PTK_OPT_BALANCE; needs the wave's WaveLds); bit 5 (with bit 3): the scene has no KD-tree
+// node (k_bounce_fused for Room-like scenes).
 template <int MODE, bool BUNDLE = false>
 __device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best, WaveLds* L)
 {
     if (MODE & 8) {
         unsigned long long unused;
-        intersect_scene_balanced<(MODE & 2) != 0, false, BUNDLE>(S, o, d, lane_on, best, *L, unused);
+        intersect_scene_balanced<(MODE & 2) != 0, false, BUNDLE, (MODE & 32) != 0>(S, o, d, lane_on, best, *L, unused);
     }
     else if ((MODE & 5) == 5) intersect_scene_lanelist<(MODE & 2) != 0, (MODE & 16) != 0>(S, o, d, lane_on, best);
     else if (MODE & 1) intersect_scene_nodelist<(MODE & 2) != 0>(S, o, d, lane_on, best);

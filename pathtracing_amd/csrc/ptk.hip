@@ -834,13 +834,22 @@ __global__ __launch_bounds__(kWalkBlock, 4) void k_walk(const DScene S, const ui
             // lanes served per instruction spent: a descend step costs about 135 VALU instructions, a pop 90,
             // a leaf stage 250 or more
             if (2u * n_node >= n_leaf && 2u * n_node >= 3u * n_pop) {
-                PTK_STAT_FINE(S, 22, 1);
-                PTK_STAT_FINE(S, 23, n_node);
-#ifdef PTK_WALK_INLINE_POP
-                if (at_node) walk_descend_step<false>(W, S, stack, stack_cap);
-#else
-                if (at_node) walk_descend_step<true>(W, S, stack, stack_cap);
-#endif
+                // a RUN of descend passes, in a loop of its own: as long as the choice stays the same the state stays in
+                // the registers it is in (as one pass per trip of the walk loop every pass copies the state into the
+                // registers the three kinds of pass share, and back)
+                bool on_node = at_node;
+                uint32_t nn = n_node;
+                for (;;) {
+                    PTK_STAT_FINE(S, 22, 1);
+                    PTK_STAT_FINE(S, 23, nn);
+                    if (on_node) walk_descend_step<true>(W, S, stack, stack_cap);
+                    const uint64_t r_pop = __builtin_amdgcn_ballot_w64(W.cur == kWalkPop);
+                    const uint64_t r_leaf = __builtin_amdgcn_ballot_w64((W.cb & kKdCountMask) != 0u);
+                    nn = (uint32_t)__popcll(m_walk & ~r_pop & ~r_leaf);
+                    const uint32_t nl = (uint32_t)__popcll(m_walk & ~r_pop & r_leaf), np = (uint32_t)__popcll(m_walk & r_pop);
+                    if (nn == 0u || !(2u * nn >= nl && 2u * nn >= 3u * np)) break; // (a descend pass ends no walk: n_walk stands)
+                    on_node = walking && W.cur != kWalkPop && (W.cb & kKdCountMask) == 0u;
+                }
                 acc_d += PTK_CLOCK() - clk_p0;
             } else if (3u * n_pop >= n_leaf) {
                 PTK_STAT_FINE(S, 29, 1);

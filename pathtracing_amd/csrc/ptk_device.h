@@ -798,8 +798,12 @@ __device__ __forceinline__ void walk_descend_step(KdWalk& W, [[maybe_unused]] co
         }
     }
     float bl, br;
-    const bool el = has_l && bl_in && !kd_prune(ly, lz, o, W.inv, W.oabs, W.best_d, bl);
-    const bool er = has_r && br_in && !kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
+    // (both prune tests unconditionally: the wave runs them anyway, and without the short-circuit they are one straight
+    // stretch of arithmetic instead of two exec-mask regions)
+    const bool pl = kd_prune(ly, lz, o, W.inv, W.oabs, W.best_d, bl);
+    const bool pr = kd_prune(ry, rz, o, W.inv, W.oabs, W.best_d, br);
+    const bool el = has_l && bl_in && !pl;
+    const bool er = has_r && br_in && !pr;
     const bool right_first = ((W.neg >> k) & 1u) != 0u;
     const bool take_r = er && (right_first || !el);
     if constexpr (DEFER_POP) {

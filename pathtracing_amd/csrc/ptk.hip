@@ -1633,7 +1633,13 @@ int kernel_mode(const ptk_ctx* c, bool primary)
     // "auto": the pooled work lists, except for the incoherent bounces of a scene of many analytic / one-leaf
     // nodes, where the wave-uniform cull over every node costs more than per-lane candidate lists
     // (materials.json, 25 spheres: k_bounce<false> 182 -> 171 us)
-    const bool many_flat_nodes = !primary && !c->deep_kd && c->S.num_nodes >= kCullMinNodes && c->traversal == 2 && c->node_cull == 2;
+#ifdef PTK_BALLS_PRIMARY_POOLED // bounce 0 of a spheres-only scene through the pooled work lists, for A/B runs
+    const bool lists_primary = false;
+#else
+    // (a spheres-only scene of at most 64 nodes: the candidate lists take a bundle pre-cull of their own for the primary rays)
+    const bool lists_primary = c->all_balls && c->S.num_nodes <= 64u;
+#endif
+    const bool many_flat_nodes = (!primary || lists_primary) && !c->deep_kd && c->S.num_nodes >= kCullMinNodes && c->traversal == 2 && c->node_cull == 2;
     if (c->balance == 1 || (c->balance == 2 && c->S.num_nodes >= kBalanceMinNodes && !many_flat_nodes))
         return 8 | ((c->kd_prune && c->deep_kd) ? 2 : 0);
     const bool cull = c->node_cull == 1 || (c->node_cull == 2 && c->S.num_nodes >= kCullMinNodes);

@@ -1061,12 +1061,39 @@ __device__ __forceinline__ void lane_hit_to_world(const float4* __restrict__ nv,
     d0 = dot(dv, dv);
 }
 
+// The bundle pre-cull's test of one node (see intersect_scene_balanced, "Bundle pre-cull"): can any ray of a wave whose
+// rays lie within eo (origins) and ed (directions, both L1) of the central ray (oc, dc) touch the node's padded world box?
+__device__ __forceinline__ bool bundle_keep(const DCull cu, V3 oc, V3 dc, float eo, float ed)
+{
+    const V3 invc = mk(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.x), -1e30f, 1e30f),
+                       __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.y), -1e30f, 1e30f),
+                       __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.z), -1e30f, 1e30f));
+    const float o1c = fabsf(oc.x) + fabsf(oc.y) + fabsf(oc.z) + eo;
+    const float m = __builtin_fmaf(cu.cull_k, o1c, cu.cull_c);
+    const float cx = 0.5f * (cu.bx[0] + cu.bx[1]), cy = 0.5f * (cu.by[0] + cu.by[1]), cz = 0.5f * (cu.bz[0] + cu.bz[1]);
+    const float R = 0.5f * ((cu.bx[1] - cu.bx[0]) + (cu.by[1] - cu.by[0]) + (cu.bz[1] - cu.bz[0])) + 3.0f * m;
+    const float T = fabsf(oc.x - cx) + fabsf(oc.y - cy) + fabsf(oc.z - cz) + eo + R;
+    const float g = 1.01f * (m + eo + T * ed) + 1e-30f; // total inflation, with slack for this arithmetic
+    const float tx0 = (cu.bx[0] - g - oc.x) * invc.x, tx1 = (cu.bx[1] + g - oc.x) * invc.x;
+    const float ty0 = (cu.by[0] - g - oc.y) * invc.y, ty1 = (cu.by[1] + g - oc.y) * invc.y;
+    const float tz0 = (cu.bz[0] - g - oc.z) * invc.z, tz1 = (cu.bz[1] + g - oc.z) * invc.z;
+    const float t_in = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    const float t_out = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)); // false on NaN = keep
+    const bool finite_box = g < 1e30f;                                         // false on NaN / overflow = keep
+    return !(finite_box && (missed || t_out < 0.0f));
+}
+
 // BALLS: every node of the scene is a sphere that carries its bounding ball in place of its world box (DNode::wmin = centre,
 // wmax[0] = radius = the largest singular value of the node's 3x3, rounded up; ptk_scene_upload sets uses_uv bit 1 and the
 // host picks this instantiation only when all nodes have it: a per-node branch between the two tests costs more than either).
 // The ball is the shape itself for a uniformly scaled sphere, so what survives the cull are (nearly) the true hits, and the
 // test is cheaper than six slab planes: materials.json +7.7 %.
-template <bool PRUNE, bool BALLS = false>
+// BUNDLE (scenes of at most 64 nodes): the wave's rays are nearly one ray (primary rays: 64 samples of a pixel), so one test per
+// node for the whole wave (lane = node, bundle_keep) first says which nodes any of them can touch; only those get the per-ray
+// test.  The rays of a coherent wave then hold the same one or two candidates, and each lane working through its own list
+// costs no more rounds than pooling them would.
+template <bool PRUNE, bool BALLS = false, bool BUNDLE = false>
 __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, V3 d, bool lane_on, Hit& best)
 {
     best.d0 = 3.402823466e+38f;
@@ -1079,11 +1106,37 @@ __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, 
     // unit direction for the ball test (callers of the parity entry may pass any length; a zero or non-finite direction
     // gives NaN here, and a NaN never culls)
     const V3 dn = d * __builtin_amdgcn_rsqf(__builtin_fmaf(d.x, d.x, __builtin_fmaf(d.y, d.y, d.z * d.z)));
+    uint64_t bundle_mask = ~0ull; // nodes 0..63 that some ray of the wave may touch
+    if (BUNDLE && S.num_nodes <= 64u) {
+        const uint32_t lane = lane_id();
+        const uint64_t live = __builtin_amdgcn_ballot_w64(lane_on);
+        const int first = live ? (int)__builtin_ctzll(live) : 0;
+        const V3 oc = mk(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o.x), first)),
+                         __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o.y), first)),
+                         __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o.z), first)));
+        const V3 dc = mk(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d.x), first)),
+                         __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d.y), first)),
+                         __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d.z), first)));
+        float eo = lane_on ? fabsf(o.x - oc.x) + fabsf(o.y - oc.y) + fabsf(o.z - oc.z) : 0.0f;
+        float ed = lane_on ? fabsf(d.x - dc.x) + fabsf(d.y - dc.y) + fabsf(d.z - dc.z) : 0.0f;
+        const bool sane = o1 + (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)) < 1e8f; // false on NaN
+        const bool ok = !lane_on || (eo < 1e30f && ed < 1e30f && sane);
+        for (int w = 32; w > 0; w >>= 1) { // wave maxima
+            eo = fmaxf(eo, __shfl_xor(eo, w));
+            ed = fmaxf(ed, __shfl_xor(ed, w));
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull && live != 0ull) {
+            bool keep = lane < S.num_nodes;
+            if (keep) keep = bundle_keep(S.cull[lane], oc, dc, eo, ed);
+            bundle_mask = __builtin_amdgcn_ballot_w64(keep);
+        }
+    }
     for (uint32_t g = 0; g < S.num_nodes; g += 32u) {
         const uint32_t gend = (S.num_nodes - g < 32u) ? S.num_nodes : g + 32u;
         uint32_t pend_sphere = 0u, pend_small = 0u, pend_leaf = 0u, pend_tree = 0u;
         // phase 1: wave-uniform, conservative
         for (uint32_t n = g; n < gend; ++n) {
+            if (BUNDLE && n < 64u && ((bundle_mask >> n) & 1ull) == 0ull) continue; // no ray of the wave can touch it
             const DNode* __restrict__ nd = S.nodes + n;
             const float m = nd->cull_k * o1 + nd->cull_c;
             bool missed, behind;
@@ -1666,26 +1719,7 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         // lane = node base + lane: central ray against the inflated box, same slab formulation as below
         const uint32_t nn = base + lane;
         bool keep = nn < S.num_nodes;
-        if (bundle_sane && keep) {
-            const DCull cu = S.cull[nn];
-            const V3 invc = mk(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.x), -1e30f, 1e30f),
-                               __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.y), -1e30f, 1e30f),
-                               __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dc.z), -1e30f, 1e30f));
-            const float o1c = fabsf(oc.x) + fabsf(oc.y) + fabsf(oc.z) + eo;
-            const float m = __builtin_fmaf(cu.cull_k, o1c, cu.cull_c);
-            const float cx = 0.5f * (cu.bx[0] + cu.bx[1]), cy = 0.5f * (cu.by[0] + cu.by[1]), cz = 0.5f * (cu.bz[0] + cu.bz[1]);
-            const float R = 0.5f * ((cu.bx[1] - cu.bx[0]) + (cu.by[1] - cu.by[0]) + (cu.bz[1] - cu.bz[0])) + 3.0f * m;
-            const float T = fabsf(oc.x - cx) + fabsf(oc.y - cy) + fabsf(oc.z - cz) + eo + R;
-            const float g = 1.01f * (m + eo + T * ed) + 1e-30f; // total inflation, with slack for this arithmetic
-            const float tx0 = (cu.bx[0] - g - oc.x) * invc.x, tx1 = (cu.bx[1] + g - oc.x) * invc.x;
-            const float ty0 = (cu.by[0] - g - oc.y) * invc.y, ty1 = (cu.by[1] + g - oc.y) * invc.y;
-            const float tz0 = (cu.bz[0] - g - oc.z) * invc.z, tz1 = (cu.bz[1] + g - oc.z) * invc.z;
-            const float t_in = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
-            const float t_out = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-            const bool missed = (t_in - t_out) > 1e-5f * (fabsf(t_in) + fabsf(t_out)); // false on NaN = keep
-            const bool finite_box = g < 1e30f;                                         // false on NaN / overflow = keep
-            keep = !(finite_box && (missed || t_out < 0.0f));
-        }
+        if (bundle_sane && keep) keep = bundle_keep(S.cull[nn], oc, dc, eo, ed);
         bundle_base = base;
         bundle_mask = __builtin_amdgcn_ballot_w64(keep);
     };
@@ -1893,7 +1927,7 @@ __device__ __forceinline__ void intersect_scene_mode(const DScene& S, V3 o, V3 d
         unsigned long long unused;
         intersect_scene_balanced<(MODE & 2) != 0, false, BUNDLE, (MODE & 32) != 0>(S, o, d, lane_on, best, *L, unused);
     }
-    else if ((MODE & 5) == 5) intersect_scene_lanelist<(MODE & 2) != 0, (MODE & 16) != 0>(S, o, d, lane_on, best);
+    else if ((MODE & 5) == 5) intersect_scene_lanelist<(MODE & 2) != 0, (MODE & 16) != 0, BUNDLE && (MODE & 16) != 0>(S, o, d, lane_on, best);
     else if (MODE & 1) intersect_scene_nodelist<(MODE & 2) != 0>(S, o, d, lane_on, best);
     else intersect_scene<(MODE & 2) != 0>(S, o, d, lane_on, best);
 }

@@ -963,6 +963,19 @@ __device__ __forceinline__ bool sphere_intersect(V3 o, V3 d, V3& p_out)
     return true;
 }
 
+// The same without early returns (see tri_eval_flat): every lane of the wave runs every operation anyway; a line that misses
+// the ball gives a NaN offset, which fails nothing that the first comparison has not already failed.
+__device__ __forceinline__ bool sphere_intersect_flat(V3 o, V3 d, V3& p_out)
+{
+    const float projection = dot(mk(0.0f, 0.0f, 0.0f) - o, d);
+    const float sq_distance = dot(o, o) - projection * projection;
+    const float offset = sqrtf(1.0f - sq_distance);
+    const float t1 = projection - offset;
+    const float t2 = projection + offset;
+    p_out = o + d * (t1 >= 0.0f ? t1 : t2);
+    return !(sq_distance > 1.0f) && !(t1 < 0 && t2 < 0);
+}
+
 // scene::cast_ray, scene.cpp:355-399.  All lanes of a wave walk the node table
 // together (there is no top-level structure in the reference: every ray tests
 // every node), so the node record and the sphere/mesh branch are wave-uniform.
@@ -1181,7 +1194,8 @@ __device__ __forceinline__ void intersect_scene_lanelist(const DScene& S, V3 o, 
             const float4* __restrict__ nv = reinterpret_cast<const float4*>(S.nodes + n);
             V3 lo, ld, p = mk(0.0f, 0.0f, 0.0f);
             lane_ray_to_local(nv, o, d, lo, ld);
-            if (work && sphere_intersect(lo, ld, p)) {
+            const bool sphere_hit = sphere_intersect_flat(lo, ld, p);
+            if (work && sphere_hit) {
                 V3 pw;
                 float d0;
                 lane_hit_to_world(nv, o, p, pw, d0);
@@ -1603,7 +1617,8 @@ __device__ __forceinline__ void intersect_scene_balanced(const DScene& S, V3 o, 
         const bool is_sphere = have && cls == kClassSphere;
         if (__builtin_amdgcn_ballot_w64(is_sphere) != 0ull) {
             V3 sp = mk(0.0f, 0.0f, 0.0f);
-            if (is_sphere && sphere_intersect(lo, ld, sp)) {
+            const bool sphere_hit = sphere_intersect_flat(lo, ld, sp);
+            if (is_sphere && sphere_hit) {
                 hit = true;
                 p = sp;
                 a = sp;

@@ -160,6 +160,12 @@ def main():
     ap.add_argument("--triangles", type=int, default=5_000_000, help="synthetic workload: triangle count")
     ap.add_argument("--resolution", type=int, nargs=2, default=None)
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when the process group comes up (seen with
+    # the nccl backend on ROCm 7), and anything else a library writes there would break a parser too: from here on file
+    # descriptor 1 is stderr, and the JSON line goes to the saved original.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     global W, H
     W, H = args.resolution or (WORKLOADS[args.workload]["w"], WORKLOADS[args.workload]["h"])
 
@@ -411,7 +417,8 @@ def main():
             }
         else:
             out["roofline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
